@@ -1,0 +1,144 @@
+/* C ABI of the MI355X (gfx950) implementation of the two data-parallel paths of Kouek/RayTracer:
+ *   path 1: LBVH build, BVH traversal / intersection, path-tracing integrator
+ *   path 2: Depth-Box VDB build, direct-volume-rendering ray marcher
+ *
+ * The reference has no FFI layer: its boundary is the public C++ API of four classes
+ * (include/ray_tracer/lbvh.h, include/ray_tracer/ray_tracer.h, include/ray_caster/dpbx_vdb.h,
+ * include/ray_caster/ray_caster.h). Each entry point below names the reference member function whose
+ * GPU work it performs; the C++ classes in include/kouek/ keep the reference's signatures and call
+ * these.
+ *
+ * Conventions
+ *   - every function returns 0 on success and a negative kk_status otherwise; kk_last_error() gives
+ *     the message of the calling thread's last failure (the reference prints and leaves
+ *     IsComplete() == false, src/ray_caster/dpbx_vdb.cu:17-22; the C++ wrappers do the same);
+ *   - pointers named d_* are device pointers, h_* host pointers; nothing here takes ownership;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream). Launchers enqueue work
+ *     and return; they neither allocate nor synchronise unless their comment says so;
+ *   - structs are plain C with the reference's memory layout where the reference has a counterpart.
+ */
+#ifndef KOUEK_HIP_H
+#define KOUEK_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum kk_status {
+    KK_OK = 0,
+    KK_ERR_INVALID = -1,   /* bad argument (null pointer, zero size, size over a limit) */
+    KK_ERR_WORKSPACE = -2, /* workspace too small */
+    KK_ERR_HIP = -3,       /* a HIP runtime call failed; see kk_last_error() */
+    KK_ERR_DEVICE = -4     /* the device reported a failure flag (e.g. a look-back spin ran out) */
+} kk_status;
+
+const char *kk_last_error(void);
+/* Compiled architecture and library version, e.g. "gfx950;0.1". */
+const char *kk_build_info(void);
+
+/* ---- plumbing for clients that own no device allocator (the C++ classes, ctypes tests) --------- */
+int kk_set_device(int device);
+int kk_malloc(void **d_ptr, size_t bytes);
+int kk_free(void *d_ptr);
+int kk_memcpy_h2d(void *d_dst, const void *h_src, size_t bytes, void *stream);
+int kk_memcpy_d2h(void *h_dst, const void *d_src, size_t bytes, void *stream);
+int kk_memset(void *d_dst, int value, size_t bytes, void *stream);
+int kk_stream_synchronize(void *stream);
+
+/* ================================================================================================
+ * Path 1a: LBVH build  --  kouek::RayTracer::LBVH::BuildFrom (src/ray_tracer/lbvh.cu:100-323)
+ * ============================================================================================== */
+
+/* include/ray_tracer/lbvh.h:24-34. MSB of lft/rht set = the child is a leaf (compact index). */
+typedef struct kk_lbvh_node {
+    uint32_t lft, rht;
+    float aabb_min[3], aabb_max[3];
+} kk_lbvh_node; /* 32 bytes */
+
+/* include/ray_tracer/lbvh.h:35-42, same offsets; lives in device memory, mirrored to the host. */
+typedef struct kk_lbvh_device_data {
+    float root_aabb_min[3], root_aabb_max[3];
+    uint32_t face_num;
+    uint32_t compacted_face_num;
+    uint32_t *faces;           /* [face_num] sorted face permutation */
+    uint32_t *compacted_faces; /* [compacted_face_num] start of each run of equal Morton codes */
+    kk_lbvh_node *internal_nodes; /* [max(compacted_face_num - 1, 1)] */
+    uint64_t _pad;
+} kk_lbvh_device_data; /* 64 bytes */
+
+#define KK_LBVH_MAX_FACES 0x3FFFFFFFu /* look-back words keep 30 bits of count */
+
+enum {
+    KK_LBVH_KEEP_STAGES = 1 /* also keep the unsorted Morton codes (one extra N*4 copy) for stage checks */
+};
+
+/* Byte offsets of the intermediate arrays inside the workspace, for stage-by-stage parity checks.
+ * Valid after kk_lbvh_build has completed on the stream. */
+typedef struct kk_lbvh_ws_layout {
+    size_t total_bytes;
+    size_t sorted_mortons;   /* uint32[N]  Morton codes in sorted order (lbvh.cu:172) */
+    size_t unsorted_mortons; /* uint32[N]  only with KK_LBVH_KEEP_STAGES (lbvh.cu:136-170) */
+    size_t unique_mortons;   /* uint32[M]  one code per leaf (lbvh.cu:202) */
+    size_t leaf_aabbs;       /* float[M][6] per-leaf boxes (lbvh.cu:204-216) */
+    size_t node_parents;     /* uint32[M-1] parent of each internal node (node 0: 0xFFFFFFFF) */
+    size_t leaf_parents;     /* uint32[M]  parent of each leaf */
+    size_t error_flag;       /* uint32     non-zero if a sort look-back gave up */
+} kk_lbvh_ws_layout;
+
+int kk_lbvh_workspace_layout(uint32_t face_num, uint32_t vert_num, uint32_t flags,
+                             kk_lbvh_ws_layout *out);
+
+/* Builds the tree on `stream`: root bounds over all vert_num positions, 30-bit Morton code of each
+ * triangle's box centre, stable radix sort, runs of equal codes -> leaves, Karras links, bottom-up
+ * box refit. No host synchronisation: M (compacted_face_num) stays on the device until the caller
+ * reads *d_out back.
+ *   d_positions      float[vert_num][3]
+ *   d_face_pos_idx   uint32[face_num][3]
+ *   d_faces          uint32[face_num]        out
+ *   d_compacted      uint32[face_num]        out (M used)
+ *   d_nodes          kk_lbvh_node[face_num]  out (max(M-1,1) used)
+ *   d_out            kk_lbvh_device_data     out; its pointers are set to the three arrays above
+ * When M == 1 the reference allocates no internal node yet its traversal reads node 0; here node 0 is
+ * then written with both children = leaf 0 and the leaf's box. face_num == 0 is rejected. */
+int kk_lbvh_build(const float *d_positions, uint32_t vert_num, const uint32_t *d_face_pos_idx,
+                  uint32_t face_num, uint32_t *d_faces, uint32_t *d_compacted,
+                  kk_lbvh_node *d_nodes, kk_lbvh_device_data *d_out, void *d_workspace,
+                  size_t workspace_bytes, uint32_t flags, void *stream);
+
+/* The sort on its own (stable, ascending, 32-bit keys with 32-bit payloads; d_vals_in == NULL means
+ * payload = index), as lbvh.cu:110,172 uses thrust::sequence + sort_by_key. Result lands in
+ * d_keys_a / d_vals_a; the *_b arrays and d_workspace (kk_sort_workspace_bytes) are scratch. */
+size_t kk_sort_workspace_bytes(uint32_t n);
+int kk_sort_pairs_u32(uint32_t *d_keys_a, uint32_t *d_keys_b, uint32_t *d_vals_a, uint32_t *d_vals_b,
+                      int vals_are_iota, uint32_t n, void *d_workspace, size_t workspace_bytes,
+                      void *stream);
+
+/* ================================================================================================
+ * Path 1b: closest hit  --  rayCastLBVH<false> (src/ray_tracer/ray_tracer_render.cu:192-270)
+ * ============================================================================================== */
+
+enum {
+    KK_TRAVERSE_ORDERED = 0 /* near child first, boxes beyond the best hit skipped; ties in t go to the
+                               smaller position in `faces`, which is the hit the reference's fixed
+                               left-to-right walk keeps */
+};
+
+/* d_rays float[R][6] (pos, dir) -> d_t float[R] (FLT_MAX on a miss), d_bary float[R][2],
+ * d_prim uint32[R] (face index, 0xFFFFFFFF on a miss). d_counters (optional, uint64[4], zeroed by the
+ * caller) accumulates node boxes fetched, triangles tested, rays traced. d_workspace holds the ray
+ * queue head (kk_closest_hit_workspace_bytes()). internal_nodes must be 16-byte aligned, as the
+ * reference's KOUEK_CUDA_ALIGN makes them. Same slab and triangle arithmetic as
+ * include/cg/ray.h:29-58. */
+size_t kk_closest_hit_workspace_bytes(void);
+int kk_closest_hit(const kk_lbvh_device_data *d_lbvh, const float *d_positions,
+                   const uint32_t *d_face_pos_idx, const float *d_rays, uint32_t ray_num, float *d_t,
+                   float *d_bary, uint32_t *d_prim, int mode, unsigned long long *d_counters,
+                   void *d_workspace, size_t workspace_bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KOUEK_HIP_H */

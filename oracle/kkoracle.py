@@ -1,0 +1,161 @@
+"""TEST INFRASTRUCTURE ONLY: ctypes access to the CPU checker (oracle/_build/libkkoracle.so) and,
+when present, to the pieces of the reference compiled as they are (oracle/_ref/libkkref.so).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the
+shipped package (raytracer_amd) never does.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "_build", "libkkoracle.so")
+_REF = os.path.join(_HERE, "_ref", "libkkref.so")
+
+_f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+_u32p = np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS")
+_u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
+_u64p = np.ctypeslib.ndpointer(dtype=np.uint64, flags="C_CONTIGUOUS")
+
+INODE_DTYPE = np.dtype([("lft", "<u4"), ("rht", "<u4"), ("aabb", "<f4", (6,))])
+assert INODE_DTYPE.itemsize == 32
+LEAF_MASK = np.uint32(0x80000000)
+FLT_MAX = np.float32(np.finfo(np.float32).max)
+
+
+def build(force: bool = False) -> None:
+    """Compile the checker (and oracle/_ref when /root/reference exists)."""
+    if force or not os.path.exists(_LIB) or not os.path.exists(_REF):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+
+
+_lib = None
+_ref = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB):
+            build()
+        _lib = C.CDLL(_LIB)
+    return _lib
+
+
+def ref():
+    """The compiled reference pieces, or None when they were never built on this tree."""
+    global _ref
+    if _ref is None and os.path.exists(_REF):
+        _ref = C.CDLL(_REF)
+    return _ref
+
+
+def _vp(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def lbvh_build(positions: np.ndarray, tri: np.ndarray, refit_mode: int = 1) -> dict:
+    pos = np.ascontiguousarray(positions, dtype=np.float32).reshape(-1, 3)
+    tri = np.ascontiguousarray(tri, dtype=np.uint32).reshape(-1, 3)
+    V, N = pos.shape[0], tri.shape[0]
+    out = {
+        "rootAABB": np.zeros(6, np.float32),
+        "mortons": np.zeros(N, np.uint32),
+        "sortedMortons": np.zeros(N, np.uint32),
+        "faces": np.zeros(N, np.uint32),
+        "compactedFaces": np.zeros(N, np.uint32),
+        "uniqueMortons": np.zeros(N, np.uint32),
+        "leafAABBs": np.zeros((N, 6), np.float32),
+        "internalNodes": np.zeros(max(N, 1), INODE_DTYPE),
+    }
+    m = C.c_uint32(0)
+    rc = lib().ko_lbvh_build(_vp(pos), C.c_uint32(V), _vp(tri), C.c_uint32(N), _vp(out["rootAABB"]),
+                             _vp(out["mortons"]), _vp(out["sortedMortons"]), _vp(out["faces"]),
+                             _vp(out["compactedFaces"]), _vp(out["uniqueMortons"]),
+                             _vp(out["leafAABBs"]), _vp(out["internalNodes"]), C.c_int(refit_mode),
+                             C.byref(m))
+    if rc != 0:
+        raise ValueError("oracle lbvh_build rejected the input (N == 0?)")
+    M = int(m.value)
+    out["M"] = M
+    out["N"] = N
+    out["compactedFaces"] = out["compactedFaces"][:M].copy()
+    out["uniqueMortons"] = out["uniqueMortons"][:M].copy()
+    out["leafAABBs"] = out["leafAABBs"][:M].copy()
+    out["internalNodes"] = out["internalNodes"][:max(M - 1, 0)].copy()
+    return out
+
+
+def closest_hit(bvh: dict, positions: np.ndarray, tri: np.ndarray, rays: np.ndarray):
+    pos = np.ascontiguousarray(positions, dtype=np.float32).reshape(-1, 3)
+    tri = np.ascontiguousarray(tri, dtype=np.uint32).reshape(-1, 3)
+    rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 6)
+    R = rays.shape[0]
+    t = np.zeros(R, np.float32)
+    bary = np.zeros((R, 2), np.float32)
+    prim = np.zeros(R, np.uint32)
+    stats = np.zeros(2, np.uint64)
+    lib().ko_closest_hit(_vp(bvh["rootAABB"]), C.c_uint32(bvh["N"]), C.c_uint32(bvh["M"]),
+                         _vp(bvh["faces"]), _vp(bvh["compactedFaces"]), _vp(bvh["internalNodes"]),
+                         _vp(pos), _vp(tri), _vp(rays), C.c_uint32(R), _vp(t), _vp(bary), _vp(prim),
+                         _vp(stats))
+    return t, bary, prim, {"node_fetches": int(stats[0]), "tri_tests": int(stats[1])}
+
+
+def check_tree_invariants(bvh: dict) -> int:
+    """The reference's own structural self-check (include/ray_tracer/test_options.h:23-96): walk from
+    node 0, every internal node, leaf and face must be reached exactly once. Returns the tree height
+    counted the way that check counts it."""
+    M, N = bvh["M"], bvh["N"]
+    nodes = bvh["internalNodes"]
+    seen_i = np.zeros(max(M - 1, 0), np.int32)
+    seen_l = np.zeros(M, np.int32)
+    seen_f = np.zeros(N, np.int32)
+    height = 0
+    if M > 1:
+        level = [0]
+        while level:
+            height += 1
+            nxt = []
+            for n in level:
+                seen_i[n] += 1
+                for ch in (int(nodes["lft"][n]), int(nodes["rht"][n])):
+                    if ch & 0x80000000:
+                        c = ch & 0x7FFFFFFF
+                        seen_l[c] += 1
+                        beg = int(bvh["compactedFaces"][c])
+                        end = N if c == M - 1 else int(bvh["compactedFaces"][c + 1])
+                        for k in range(beg, end):
+                            seen_f[bvh["faces"][k]] += 1
+                    else:
+                        nxt.append(ch)
+            level = nxt
+        assert (seen_i == 1).all(), "an internal node is not reached exactly once"
+        assert (seen_l == 1).all(), "a leaf is not reached exactly once"
+        assert (seen_f == 1).all(), "a face is not reached exactly once"
+    return height
+
+
+# ---- single primitives, for the glm cross-check -------------------------------------------------
+
+def _call(fn, *arrays_and_out):
+    fn(*[_vp(a) for a in arrays_and_out])
+    return arrays_and_out[-1]
+
+
+def hit_triangle(ray6, tri9, which="oracle"):
+    out = np.zeros(3, np.float32)
+    l = lib() if which == "oracle" else ref()
+    f = l.ko_hit_triangle if which == "oracle" else l.kkref_hit_triangle
+    return _call(f, np.ascontiguousarray(ray6, np.float32), np.ascontiguousarray(tri9, np.float32), out)
+
+
+def hit_aabb(ray6, aabb6, which="oracle"):
+    out = np.zeros(2, np.float32)
+    l = lib() if which == "oracle" else ref()
+    f = l.ko_hit_aabb if which == "oracle" else l.kkref_hit_aabb
+    return _call(f, np.ascontiguousarray(ray6, np.float32), np.ascontiguousarray(aabb6, np.float32), out)

@@ -1,0 +1,81 @@
+"""ctypes binding of lib/libkouek_hip.so. There is no fallback: if the library is missing or a call
+fails, an exception is raised."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libkouek_hip.so")
+
+
+class KoukeError(RuntimeError):
+    pass
+
+
+class LbvhWsLayout(C.Structure):
+    _fields_ = [(n, C.c_size_t) for n in ("total_bytes", "sorted_mortons", "unsorted_mortons",
+                                          "unique_mortons", "leaf_aabbs", "node_parents",
+                                          "leaf_parents", "error_flag")]
+
+
+class LbvhDeviceData(C.Structure):
+    _fields_ = [("root_aabb_min", C.c_float * 3), ("root_aabb_max", C.c_float * 3),
+                ("face_num", C.c_uint32), ("compacted_face_num", C.c_uint32),
+                ("faces", C.c_uint64), ("compacted_faces", C.c_uint64),
+                ("internal_nodes", C.c_uint64), ("_pad", C.c_uint64)]
+
+
+assert C.sizeof(LbvhDeviceData) == 64
+
+KK_LBVH_KEEP_STAGES = 1
+KK_TRAVERSE_ORDERED = 0
+
+_lib = None
+
+
+def build_library(force: bool = False) -> str:
+    """Compile the HIP sources for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    if force or not os.path.exists(LIB_PATH):
+        subprocess.check_call(["make", "-C", os.path.join(_HERE, "csrc"), "-s", "-j8"])
+    return LIB_PATH
+
+
+def _declare(l):
+    vp, u32, sz, i32 = C.c_void_p, C.c_uint32, C.c_size_t, C.c_int
+    l.kk_last_error.restype = C.c_char_p
+    l.kk_build_info.restype = C.c_char_p
+    l.kk_sort_workspace_bytes.restype = sz
+    l.kk_sort_workspace_bytes.argtypes = [u32]
+    l.kk_sort_pairs_u32.argtypes = [vp, vp, vp, vp, i32, u32, vp, sz, vp]
+    l.kk_lbvh_workspace_layout.argtypes = [u32, u32, u32, C.POINTER(LbvhWsLayout)]
+    l.kk_lbvh_build.argtypes = [vp, u32, vp, u32, vp, vp, vp, vp, vp, sz, u32, vp]
+    l.kk_closest_hit_workspace_bytes.restype = sz
+    l.kk_closest_hit.argtypes = [vp, vp, vp, vp, u32, vp, vp, vp, i32, vp, vp, sz, vp]
+    for name in ("kk_malloc", "kk_free", "kk_memcpy_h2d", "kk_memcpy_d2h", "kk_memset",
+                 "kk_stream_synchronize", "kk_set_device"):
+        getattr(l, name).restype = i32
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise KoukeError(
+                f"{LIB_PATH} is missing: build it with `make -C raytracer_amd/csrc` "
+                "(or __graft_entry__.build()). There is no CPU fallback.")
+        _lib = C.CDLL(LIB_PATH)
+        _declare(_lib)
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib().kk_last_error().decode(errors="replace")
+        raise KoukeError(f"{what} failed ({rc}): {msg}")
+
+
+def current_stream_ptr() -> int:
+    import torch
+    return int(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,311 @@
+// Stable LSD radix sort of (uint32 key, uint32 payload) pairs for gfx950: one histogram pass over the
+// keys, then four 8-bit "onesweep" passes. Replaces thrust::sequence + thrust::sort_by_key of
+// src/ray_tracer/lbvh.cu:110,172 (stable: equal Morton codes keep ascending face index).
+//
+// One pass, per 4096-key tile (256 threads = 4 waves, 16 keys per lane):
+//   1. the tile takes its number from an atomic counter, so every lower-numbered tile has already
+//      started and the look-back below cannot wait on a tile that is not running;
+//   2. each wave ranks its 1024 keys among equal digits with eight 64-lane ballots per key
+//      (match-any) and a per-wave digit counter in LDS;
+//   3. thread d owns digit d: sums the four wave counters, publishes the tile's count for the digit
+//      (AGGREGATE) in the tile's status row, walks back over earlier tiles' rows until it meets an
+//      INCLUSIVE word, then publishes its own inclusive count. A status word is flag(2 bits) +
+//      count(30 bits) in one 32-bit agent-scope atomic, so it needs no fence;
+//   4. keys and payloads are first scattered into LDS in tile-sorted order, then streamed out so that
+//      each run of equal digits is written to consecutive addresses (coalesced stores).
+// HBM traffic per key: 4 B (histogram) + 4 x (8 B read + 8 B write) = 68 B.
+#include "kk_host.h"
+
+namespace kk {
+namespace rsort {
+
+constexpr int THREADS = 256;
+constexpr int WAVES = THREADS / 64;
+constexpr int ITEMS = 16;
+constexpr int TILE = THREADS * ITEMS;
+constexpr int RADIX = 256;
+constexpr int PASSES = 4;
+constexpr uint32_t FLAG_AGG = 0x40000000u;
+constexpr uint32_t FLAG_INC = 0x80000000u;
+constexpr uint32_t FLAG_MASK = 0xC0000000u;
+constexpr uint32_t VALUE_MASK = 0x3FFFFFFFu;
+constexpr uint32_t SPIN_LIMIT = 1u << 22;
+
+static_assert(THREADS == RADIX, "thread d owns digit d");
+
+__device__ __forceinline__ uint32_t ld_status(const uint32_t *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_status(uint32_t *p, uint32_t v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t t = __shfl_up(v, o, 64);
+        if (lane >= o)
+            v += t;
+    }
+    return v;
+}
+
+// Exclusive scan of one value per thread over the 256-thread block. s_tmp holds WAVES words.
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *s_tmp, int tid) {
+    const int lane = tid & 63, wave = tid >> 6;
+    uint32_t incl = wave_inclusive_scan(v, lane);
+    if (lane == 63)
+        s_tmp[wave] = incl;
+    __syncthreads();
+    uint32_t prefix = 0;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w)
+        if (w < wave)
+            prefix += s_tmp[w];
+    __syncthreads();
+    return prefix + incl - v;
+}
+
+// ghist[p][d] += number of keys whose digit p equals d, for all four digits in one read of the keys.
+__global__ __launch_bounds__(THREADS) void histogram_kernel(const uint32_t *__restrict__ keys,
+                                                            uint32_t n,
+                                                            uint32_t *__restrict__ ghist) {
+    __shared__ uint32_t s_h[PASSES * RADIX];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < PASSES * RADIX; i += THREADS)
+        s_h[i] = 0;
+    __syncthreads();
+    const uint32_t n4 = n / 4;
+    const uint4 *keys4 = reinterpret_cast<const uint4 *>(keys);
+    for (uint32_t i = blockIdx.x * THREADS + tid; i < n4; i += gridDim.x * THREADS) {
+        uint4 k = keys4[i];
+        uint32_t kk4[4] = {k.x, k.y, k.z, k.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            atomicAdd(&s_h[kk4[j] & 255u], 1u);
+            atomicAdd(&s_h[RADIX + ((kk4[j] >> 8) & 255u)], 1u);
+            atomicAdd(&s_h[2 * RADIX + ((kk4[j] >> 16) & 255u)], 1u);
+            atomicAdd(&s_h[3 * RADIX + (kk4[j] >> 24)], 1u);
+        }
+    }
+    if (blockIdx.x == 0 && tid < static_cast<int>(n - n4 * 4)) {
+        uint32_t k = keys[n4 * 4 + tid];
+        atomicAdd(&s_h[k & 255u], 1u);
+        atomicAdd(&s_h[RADIX + ((k >> 8) & 255u)], 1u);
+        atomicAdd(&s_h[2 * RADIX + ((k >> 16) & 255u)], 1u);
+        atomicAdd(&s_h[3 * RADIX + (k >> 24)], 1u);
+    }
+    __syncthreads();
+    for (int i = tid; i < PASSES * RADIX; i += THREADS) {
+        uint32_t c = s_h[i];
+        if (c)
+            atomicAdd(&ghist[i], c);
+    }
+}
+
+template <bool IOTA>
+__global__ __launch_bounds__(THREADS) void onesweep_pass_kernel(
+    const uint32_t *__restrict__ keysIn, const uint32_t *__restrict__ valsIn,
+    uint32_t *__restrict__ keysOut, uint32_t *__restrict__ valsOut, uint32_t n, uint32_t shift,
+    const uint32_t *__restrict__ ghist, uint32_t *tileStatus, uint32_t *tileCounter,
+    uint32_t *errorFlag) {
+    __shared__ uint32_t s_keys[TILE];
+    __shared__ uint32_t s_vals[TILE];
+    __shared__ uint32_t s_whist[WAVES][RADIX];
+    __shared__ uint32_t s_digitStart[RADIX];
+    __shared__ uint32_t s_globalBase[RADIX];
+    __shared__ uint32_t s_tmp[WAVES];
+    __shared__ uint32_t s_tile;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+
+    if (tid == 0)
+        s_tile = atomicAdd(tileCounter, 1u);
+    for (int i = tid; i < WAVES * RADIX; i += THREADS)
+        (&s_whist[0][0])[i] = 0;
+    __syncthreads();
+    const uint32_t tile = s_tile;
+    const uint32_t tileBase = tile * TILE;
+
+    // 1. load: wave w owns keys [tileBase + 1024 w, +1024), item i of lane l is key 64 i + l of those
+    uint32_t key[ITEMS], val[ITEMS];
+    const uint32_t base = tileBase + wave * (ITEMS * 64) + lane;
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const uint32_t idx = base + i * 64;
+        const bool valid = idx < n;
+        key[i] = valid ? keysIn[idx] : 0xFFFFFFFFu;
+        if (IOTA)
+            val[i] = idx;
+        else
+            val[i] = valid ? valsIn[idx] : 0u;
+    }
+
+    // 2. rank among equal digits inside the wave, in key order
+    uint32_t rank[ITEMS];
+    uint32_t *whist = s_whist[wave];
+    const unsigned long long lanesBelow = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const uint32_t d = (key[i] >> shift) & 255u;
+        unsigned long long peers = ~0ull;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const bool bit = (d >> b) & 1u;
+            const unsigned long long bal = __ballot(bit);
+            peers &= bit ? bal : ~bal;
+        }
+        const int leader = __ffsll(static_cast<long long>(peers)) - 1;
+        const uint32_t cnt = __popcll(peers);
+        const uint32_t below = __popcll(peers & lanesBelow);
+        uint32_t prev = 0;
+        if (lane == leader) {
+            prev = whist[d];
+            whist[d] = prev + cnt;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        prev = __shfl(prev, leader, 64);
+        rank[i] = prev + below;
+    }
+    __syncthreads();
+
+    // 3. thread d owns digit d
+    {
+        const int d = tid;
+        uint32_t c[WAVES];
+        uint32_t total = 0;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) {
+            c[w] = s_whist[w][d];
+            s_whist[w][d] = total; // exclusive over waves
+            total += c[w];
+        }
+        const uint32_t dstart = block_exclusive_scan(total, s_tmp, tid);
+        const uint32_t gstart = block_exclusive_scan(ghist[d], s_tmp, tid);
+        s_digitStart[d] = dstart;
+
+        uint32_t *row = tileStatus + static_cast<size_t>(tile) * RADIX + d;
+        uint32_t exclusive = 0;
+        if (tile == 0) {
+            st_status(row, total | FLAG_INC);
+        } else {
+            st_status(row, total | FLAG_AGG);
+            uint32_t t = tile - 1;
+            uint32_t spins = 0;
+            while (true) {
+                const uint32_t s = ld_status(tileStatus + static_cast<size_t>(t) * RADIX + d);
+                const uint32_t f = s & FLAG_MASK;
+                if (f == 0) {
+                    if (++spins > SPIN_LIMIT) {
+                        atomicOr(errorFlag, 1u);
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(2);
+                    continue;
+                }
+                exclusive += s & VALUE_MASK;
+                if (f == FLAG_INC || t == 0)
+                    break;
+                --t;
+            }
+            st_status(row, ((exclusive + total) & VALUE_MASK) | FLAG_INC);
+        }
+        s_globalBase[d] = gstart + exclusive - dstart;
+    }
+    __syncthreads();
+
+    // 4. scatter into LDS in tile-sorted order, then stream out
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const uint32_t d = (key[i] >> shift) & 255u;
+        const uint32_t p = s_digitStart[d] + s_whist[wave][d] + rank[i];
+        s_keys[p] = key[i];
+        s_vals[p] = val[i];
+    }
+    __syncthreads();
+    const uint32_t remaining = n - tileBase;
+    const uint32_t validCount = remaining < static_cast<uint32_t>(TILE) ? remaining : TILE;
+    for (uint32_t j = tid; j < validCount; j += THREADS) {
+        const uint32_t k = s_keys[j];
+        const uint32_t d = (k >> shift) & 255u;
+        const uint32_t dst = s_globalBase[d] + j;
+        keysOut[dst] = k;
+        valsOut[dst] = s_vals[j];
+    }
+}
+
+struct SortWs {
+    size_t ghist, counters, error, status, total;
+    uint32_t tiles;
+};
+
+inline SortWs sort_ws(uint32_t n) {
+    SortWs w;
+    Carver c;
+    w.tiles = div_up(n, TILE);
+    w.ghist = c.take(sizeof(uint32_t) * PASSES * RADIX);
+    w.counters = c.take(sizeof(uint32_t) * PASSES);
+    w.error = c.take(sizeof(uint32_t));
+    w.status = c.take(sizeof(uint32_t) * PASSES * static_cast<size_t>(w.tiles) * RADIX);
+    w.total = c.off;
+    return w;
+}
+
+// Enqueues the whole sort. errorFlagOut (optional) receives the device address of the error word.
+int sort_pairs(uint32_t *keysA, uint32_t *keysB, uint32_t *valsA, uint32_t *valsB, bool iota,
+               uint32_t n, void *ws, size_t wsBytes, hipStream_t stream, uint32_t **errorFlagOut) {
+    SortWs w = sort_ws(n);
+    if (wsBytes < w.total) {
+        set_error("sort workspace too small: %zu < %zu", wsBytes, w.total);
+        return KK_ERR_WORKSPACE;
+    }
+    char *b = static_cast<char *>(ws);
+    uint32_t *ghist = reinterpret_cast<uint32_t *>(b + w.ghist);
+    uint32_t *counters = reinterpret_cast<uint32_t *>(b + w.counters);
+    uint32_t *error = reinterpret_cast<uint32_t *>(b + w.error);
+    uint32_t *status = reinterpret_cast<uint32_t *>(b + w.status);
+    if (errorFlagOut)
+        *errorFlagOut = error;
+    // ghist, counters, error and the status rows are contiguous pieces of one allocation
+    KK_HIP_TRY(hipMemsetAsync(b, 0, w.total, stream));
+
+    const uint32_t hgrid = w.tiles < 2048u ? (w.tiles ? w.tiles : 1u) : 2048u;
+    histogram_kernel<<<hgrid, THREADS, 0, stream>>>(keysA, n, ghist);
+    KK_LAUNCH_CHECK();
+
+    uint32_t *kin = keysA, *kout = keysB, *vin = valsA, *vout = valsB;
+    for (int p = 0; p < PASSES; ++p) {
+        uint32_t *st = status + static_cast<size_t>(p) * w.tiles * RADIX;
+        if (p == 0 && iota)
+            onesweep_pass_kernel<true><<<w.tiles, THREADS, 0, stream>>>(
+                kin, nullptr, kout, vout, n, 8u * p, ghist + p * RADIX, st, counters + p, error);
+        else
+            onesweep_pass_kernel<false><<<w.tiles, THREADS, 0, stream>>>(
+                kin, vin, kout, vout, n, 8u * p, ghist + p * RADIX, st, counters + p, error);
+        KK_LAUNCH_CHECK();
+        uint32_t *t = kin;
+        kin = kout;
+        kout = t;
+        t = vin;
+        vin = vout;
+        vout = t;
+    }
+    return KK_OK;
+}
+
+} // namespace rsort
+} // namespace kk
+
+extern "C" size_t kk_sort_workspace_bytes(uint32_t n) { return kk::rsort::sort_ws(n).total; }
+
+extern "C" int kk_sort_pairs_u32(uint32_t *d_keys_a, uint32_t *d_keys_b, uint32_t *d_vals_a,
+                                 uint32_t *d_vals_b, int vals_are_iota, uint32_t n,
+                                 void *d_workspace, size_t workspace_bytes, void *stream) {
+    KK_REQUIRE(d_keys_a && d_keys_b && d_vals_a && d_vals_b && d_workspace, "null pointer");
+    KK_REQUIRE(n > 0 && n <= KK_LBVH_MAX_FACES, "n out of range");
+    return kk::rsort::sort_pairs(d_keys_a, d_keys_b, d_vals_a, d_vals_b, vals_are_iota != 0, n,
+                                 d_workspace, workspace_bytes, static_cast<hipStream_t>(stream),
+                                 nullptr);
+}

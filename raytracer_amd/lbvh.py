@@ -1,0 +1,145 @@
+"""Host-side mirror of kouek::RayTracer::LBVH (include/ray_tracer/lbvh.h:20-78) for Python callers.
+
+Method names follow the reference (BuildFrom, IsComplete, GetDeviceData, GetDeivceDataDevicePtr - the
+misspelling is the reference's). Device memory is held in torch tensors; the build itself is
+kk_lbvh_build in the C-ABI library.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import sys
+
+import numpy as np
+import torch
+
+from . import _lib
+
+NODE_DTYPE = np.dtype([("lft", "<u4"), ("rht", "<u4"), ("aabb", "<f4", (6,))])
+LEAF_MASK = 0x80000000
+
+
+def _to_device(a, dtype, device):
+    if isinstance(a, torch.Tensor):
+        return a.to(device=device, dtype=dtype).contiguous()
+    return torch.from_numpy(np.ascontiguousarray(a)).to(device=device, dtype=dtype).contiguous()
+
+
+class LBVH:
+    StatTag = "[LBVH Status]"
+    ErrTag = "[LBVH Error]"
+
+    def __init__(self, device="cuda:0", verbose: bool = False):
+        self.device = torch.device(device)
+        self.verbose = verbose
+        self._complete = False
+        self._clear()
+
+    def _clear(self):
+        self.d_positions = self.d_face_pos_idx = None
+        self.d_faces = self.d_compacted = self.d_nodes = None
+        self.d_device_data = self.d_workspace = None
+        self._host_dd = None
+        self.ws_layout = None
+        self.face_num = 0
+
+    # -- reference API ---------------------------------------------------------------------------
+    def BuildFrom(self, positions, face_position_indices, keep_stages: bool = False,
+                  sync: bool = True) -> None:
+        """positions float32 [V,3], face_position_indices uint32 [N,3] (numpy or torch). On failure a
+        message is printed and IsComplete() stays False, as in the reference."""
+        self._complete = False
+        self._clear()
+        try:
+            self._build(positions, face_position_indices, keep_stages, sync)
+        except _lib.KoukeError as e:
+            print(f"{self.ErrTag} {e}", file=sys.stderr)
+            return
+        self._complete = True
+        if self.verbose and sync:
+            dd = self.GetDeviceData()
+            print(f"{self.StatTag} Builded LBVH.\n\tcompact num: {dd['compactedFaceNum']}, "
+                  f"face num: {dd['faceNum']}")
+
+    def IsComplete(self) -> bool:
+        return self._complete
+
+    def GetDeivceDataDevicePtr(self) -> int:
+        return 0 if self.d_device_data is None else self.d_device_data.data_ptr()
+
+    def GetDeviceData(self) -> dict:
+        """Host copy of the 64-byte DeviceData (synchronises)."""
+        if self._host_dd is None:
+            raw = self.d_device_data.cpu().numpy().tobytes()
+            dd = _lib.LbvhDeviceData.from_buffer_copy(raw)
+            self._host_dd = {
+                "rootAABB": np.array(list(dd.root_aabb_min) + list(dd.root_aabb_max), np.float32),
+                "faceNum": int(dd.face_num), "compactedFaceNum": int(dd.compacted_face_num),
+                "faces": int(dd.faces), "compactedFaces": int(dd.compacted_faces),
+                "internalNodes": int(dd.internal_nodes),
+            }
+        return self._host_dd
+
+    # -- implementation --------------------------------------------------------------------------
+    def _build(self, positions, tri, keep_stages, sync):
+        l = _lib.lib()
+        dev = self.device
+        self.d_positions = _to_device(positions, torch.float32, dev).reshape(-1, 3)
+        tri_t = tri if isinstance(tri, torch.Tensor) else torch.from_numpy(
+            np.ascontiguousarray(tri).astype(np.uint32, copy=False).view(np.int32))
+        self.d_face_pos_idx = tri_t.to(device=dev).contiguous().view(torch.int32).reshape(-1, 3)
+        V, N = self.d_positions.shape[0], self.d_face_pos_idx.shape[0]
+        if N == 0 or V == 0:
+            raise _lib.KoukeError("empty mesh: the build needs at least one face")
+        self.face_num = N
+        flags = _lib.KK_LBVH_KEEP_STAGES if keep_stages else 0
+        lay = _lib.LbvhWsLayout()
+        _lib.check(l.kk_lbvh_workspace_layout(N, V, flags, C.byref(lay)), "kk_lbvh_workspace_layout")
+        self.ws_layout = lay
+        self.d_faces = torch.empty(N, dtype=torch.int32, device=dev)
+        self.d_compacted = torch.empty(N, dtype=torch.int32, device=dev)
+        self.d_nodes = torch.empty(N * 32, dtype=torch.uint8, device=dev)
+        self.d_device_data = torch.zeros(64, dtype=torch.uint8, device=dev)
+        self.d_workspace = torch.empty(lay.total_bytes, dtype=torch.uint8, device=dev)
+        self.rebuild(flags)
+        if sync:
+            torch.cuda.synchronize(dev)
+            err = self.stage("error_flag", 1, np.uint32)
+            if int(err[0]) != 0:
+                raise _lib.KoukeError("radix sort look-back gave up (device error flag set)")
+
+    def rebuild(self, flags: int = 0) -> None:
+        """Enqueue the build again on the current stream over the same buffers (no allocation, no
+        synchronisation)."""
+        l = _lib.lib()
+        self._host_dd = None
+        with torch.cuda.device(self.device):
+            _lib.check(l.kk_lbvh_build(self.d_positions.data_ptr(), self.d_positions.shape[0],
+                                       self.d_face_pos_idx.data_ptr(), self.face_num,
+                                       self.d_faces.data_ptr(), self.d_compacted.data_ptr(),
+                                       self.d_nodes.data_ptr(), self.d_device_data.data_ptr(),
+                                       self.d_workspace.data_ptr(), self.d_workspace.numel(), flags,
+                                       _lib.current_stream_ptr()), "kk_lbvh_build")
+
+    # -- read-back helpers (parity tests, logs) --------------------------------------------------------
+    def stage(self, name: str, count: int, dtype) -> np.ndarray:
+        off = getattr(self.ws_layout, name)
+        nbytes = int(count) * np.dtype(dtype).itemsize
+        return self.d_workspace[off:off + nbytes].cpu().numpy().view(dtype).copy()
+
+    def to_host(self, keep_stages: bool = False) -> dict:
+        dd = self.GetDeviceData()
+        N, M = dd["faceNum"], dd["compactedFaceNum"]
+        out = {
+            "N": N, "M": M, "rootAABB": dd["rootAABB"],
+            "faces": self.d_faces.cpu().numpy().view(np.uint32).copy(),
+            "compactedFaces": self.d_compacted[:M].cpu().numpy().view(np.uint32).copy(),
+            "internalNodes": self.d_nodes[:max(M - 1, 1) * 32].cpu().numpy().view(NODE_DTYPE).copy(),
+            "sortedMortons": self.stage("sorted_mortons", N, np.uint32),
+            "uniqueMortons": self.stage("unique_mortons", M, np.uint32),
+            "leafAABBs": self.stage("leaf_aabbs", 6 * M, np.float32).reshape(M, 6),
+            "nodeParents": self.stage("node_parents", max(M - 1, 0), np.uint32),
+            "leafParents": self.stage("leaf_parents", M, np.uint32),
+        }
+        if keep_stages:
+            out["mortons"] = self.stage("unsorted_mortons", N, np.uint32)
+        return out
