@@ -8,7 +8,8 @@
 //   count_heads/scan/compact    : run starts of equal codes -> leaves          (algorithm.h:11-41)
 //   leaf_aabb                   : one box per run                              (lbvh.cu:186-219)
 //   karras_links                : children of each internal node (+ parents)   (lbvh.cu:29-98,221-260)
-//   refit                       : bottom-up box union with one arrival counter per internal node.
+//   refit_local + refit_top     : bottom-up box union with one arrival counter per internal node
+//                                 (in LDS inside a workgroup's leaf window, global above it).
 //                                 The reference walks each node's whole subtree (lbvh.cu:265-297);
 //                                 min/max unions are exact, so both give the same bits.
 #include "kk_host.h"
@@ -325,7 +326,7 @@ __device__ __forceinline__ int delta(const uint32_t *__restrict__ m, uint32_t mi
 __global__ __launch_bounds__(THREADS) void karras_links_kernel(
     const uint32_t *__restrict__ mortons, const kk_lbvh_device_data *__restrict__ hdr,
     kk_lbvh_node *__restrict__ nodes, uint32_t *__restrict__ nodeParents,
-    uint32_t *__restrict__ leafParents) {
+    uint32_t *__restrict__ leafParents, uint32_t *__restrict__ rangeEnds) {
     const uint32_t M = hdr->compacted_face_num;
     const int64_t inodeNum = static_cast<int64_t>(M) - 1;
     const int64_t i = static_cast<int64_t>(blockIdx.x) * THREADS + threadIdx.x;
@@ -381,6 +382,7 @@ __global__ __launch_bounds__(THREADS) void karras_links_kernel(
         nodeParents[rht] = static_cast<uint32_t>(i);
     nodes[i].lft = lft;
     nodes[i].rht = rht;
+    rangeEnds[i] = static_cast<uint32_t>(iMax); // the node covers leaves [min(i, iMax), max(i, iMax)]
     if (i == 0)
         nodeParents[0] = 0xFFFFFFFFu;
 }
@@ -392,59 +394,127 @@ __device__ __forceinline__ AABB load_box(const float *p) {
     return b;
 }
 
-// One thread per leaf climbs towards the root. Each internal node has an arrival counter: the first
-// child to arrive stops, the second one unions both children's boxes and climbs on. The counter is an
-// acquire-release agent-scope atomic, so the first child's box stores are visible to the second.
-__global__ __launch_bounds__(THREADS) void refit_kernel(const float *__restrict__ leafAABBs,
-                                                        const kk_lbvh_device_data *__restrict__ hdr,
-                                                        kk_lbvh_node *nodes,
-                                                        const uint32_t *__restrict__ nodeParents,
-                                                        const uint32_t *__restrict__ leafParents,
-                                                        uint32_t *arrivals) {
+// Bottom-up box refit in two kernels. Every internal node has an arrival counter: the first child to
+// arrive stops, the second one unions both children's boxes and climbs on.
+//   refit_local : one workgroup owns REFIT_LEAVES consecutive leaves (consecutive in Morton order, so
+//                 almost every subtree above them lies inside the group). While a parent's leaf range
+//                 lies inside the group's leaves, its counter and the boxes of the group's internal
+//                 nodes live in LDS (a node's index is an end of its range, so it falls inside the
+//                 group's window too); only finished boxes go to memory, with plain stores and no
+//                 fence. A thread whose parent straddles a group boundary appends its child to a work
+//                 list and stops.
+//   refit_top   : the listed children (about 1 % of the nodes, the top of the tree) climb on with
+//                 global counters. A counter is an acquire-release agent-scope atomic: the arriving
+//                 thread wrote its child's box itself (or an earlier kernel did), the release publishes
+//                 it, and the second arrival's acquire makes the sibling's box visible.
+constexpr int REFIT_LPT = 4;
+constexpr int REFIT_LEAVES = THREADS * REFIT_LPT;
+constexpr int REFIT_TOP_BLOCKS = 1024;
+
+__device__ __forceinline__ void store_box(float *p, const AABB &b) {
+    p[0] = b.minPos.x;
+    p[1] = b.minPos.y;
+    p[2] = b.minPos.z;
+    p[3] = b.maxPos.x;
+    p[4] = b.maxPos.y;
+    p[5] = b.maxPos.z;
+}
+
+__global__ __launch_bounds__(THREADS) void refit_local_kernel(
+    const float *__restrict__ leafAABBs, const kk_lbvh_device_data *__restrict__ hdr,
+    kk_lbvh_node *nodes, const uint32_t *__restrict__ nodeParents,
+    const uint32_t *__restrict__ leafParents, const uint32_t *__restrict__ rangeEnds,
+    uint32_t *__restrict__ topList, uint32_t *topCount) {
+    __shared__ uint32_t s_cnt[REFIT_LEAVES];
+    __shared__ float s_box[REFIT_LEAVES][6];
     const uint32_t M = hdr->compacted_face_num;
-    const uint32_t c = blockIdx.x * THREADS + threadIdx.x;
-    if (c >= M)
+    const uint32_t b0 = blockIdx.x * REFIT_LEAVES;
+    if (b0 >= M)
         return;
+    const uint32_t b1 = (b0 + REFIT_LEAVES < M) ? b0 + REFIT_LEAVES : M; // leaves [b0, b1)
+    for (int i = threadIdx.x; i < REFIT_LEAVES; i += THREADS)
+        s_cnt[i] = 0;
+    __syncthreads();
     if (M == 1) {
         // No internal node exists; give traversal a root whose two children are the only leaf.
-        nodes[0].lft = LEAF;
-        nodes[0].rht = LEAF;
-        for (int k = 0; k < 3; ++k) {
-            nodes[0].aabb_min[k] = leafAABBs[k];
-            nodes[0].aabb_max[k] = leafAABBs[3 + k];
+        if (threadIdx.x == 0) {
+            nodes[0].lft = LEAF;
+            nodes[0].rht = LEAF;
+            for (int k = 0; k < 3; ++k) {
+                nodes[0].aabb_min[k] = leafAABBs[k];
+                nodes[0].aabb_max[k] = leafAABBs[3 + k];
+            }
         }
         return;
     }
-    uint32_t child = c | LEAF;
-    uint32_t node = leafParents[c];
-    for (int guard = 0; guard < 64; ++guard) {
-        const uint32_t old =
-            __hip_atomic_fetch_add(&arrivals[node], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        if (old == 0)
-            return;
-        const uint32_t lft = nodes[node].lft, rht = nodes[node].rht;
-        AABB box = AABB::Initial();
-        box.Expand((lft & LEAF) ? load_box(leafAABBs + 6ull * (lft & LEAF_MASK))
-                                : load_box(nodes[lft].aabb_min));
-        box.Expand((rht & LEAF) ? load_box(leafAABBs + 6ull * (rht & LEAF_MASK))
-                                : load_box(nodes[rht].aabb_min));
-        nodes[node].aabb_min[0] = box.minPos.x;
-        nodes[node].aabb_min[1] = box.minPos.y;
-        nodes[node].aabb_min[2] = box.minPos.z;
-        nodes[node].aabb_max[0] = box.maxPos.x;
-        nodes[node].aabb_max[1] = box.maxPos.y;
-        nodes[node].aabb_max[2] = box.maxPos.z;
-        if (node == 0)
-            return;
-        child = node;
-        node = nodeParents[node];
+    for (int j = 0; j < REFIT_LPT; ++j) {
+        const uint32_t c = b0 + j * THREADS + threadIdx.x;
+        if (c >= b1)
+            continue;
+        AABB box = load_box(leafAABBs + 6ull * c);
+        uint32_t child = c | LEAF;
+        uint32_t node = leafParents[c];
+        for (int guard = 0; guard < 64; ++guard) {
+            const uint32_t other = rangeEnds[node];
+            const uint32_t lo = node < other ? node : other, hi = node < other ? other : node;
+            if (!(lo >= b0 && hi < b1)) {
+                topList[atomicAdd(topCount, 1u)] = child;
+                break;
+            }
+            const uint32_t lft = nodes[node].lft, rht = nodes[node].rht;
+            const uint32_t up = nodeParents[node];
+            const uint32_t sibling = (lft == child) ? rht : lft;
+            // LDS only: the box written below and this counter are both LDS accesses of one wave and
+            // are performed in order, so a workgroup-scope fence over LDS is all the ordering needed.
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+            const uint32_t old = __hip_atomic_fetch_add(&s_cnt[node - b0], 1u, __ATOMIC_RELAXED,
+                                                        __HIP_MEMORY_SCOPE_WORKGROUP);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+            if (old == 0)
+                break;
+            box.Expand((sibling & LEAF) ? load_box(leafAABBs + 6ull * (sibling & LEAF_MASK))
+                                        : load_box(s_box[sibling - b0]));
+            store_box(s_box[node - b0], box);
+            store_box(nodes[node].aabb_min, box);
+            if (node == 0)
+                break;
+            child = node;
+            node = up;
+        }
     }
-    (void)child;
+}
+
+__global__ __launch_bounds__(THREADS) void refit_top_kernel(
+    const float *__restrict__ leafAABBs, kk_lbvh_node *nodes,
+    const uint32_t *__restrict__ nodeParents, const uint32_t *__restrict__ leafParents,
+    const uint32_t *__restrict__ topList, const uint32_t *__restrict__ topCount,
+    uint32_t *arrivals) {
+    const uint32_t count = *topCount;
+    for (uint32_t e = blockIdx.x * THREADS + threadIdx.x; e < count; e += gridDim.x * THREADS) {
+        uint32_t child = topList[e];
+        uint32_t node = (child & LEAF) ? leafParents[child & LEAF_MASK] : nodeParents[child];
+        for (int guard = 0; guard < 64; ++guard) {
+            const uint32_t old = __hip_atomic_fetch_add(&arrivals[node], 1u, __ATOMIC_ACQ_REL,
+                                                        __HIP_MEMORY_SCOPE_AGENT);
+            if (old == 0)
+                break;
+            const uint32_t lft = nodes[node].lft, rht = nodes[node].rht;
+            AABB box = (lft & LEAF) ? load_box(leafAABBs + 6ull * (lft & LEAF_MASK))
+                                    : load_box(nodes[lft].aabb_min);
+            box.Expand((rht & LEAF) ? load_box(leafAABBs + 6ull * (rht & LEAF_MASK))
+                                    : load_box(nodes[rht].aabb_min));
+            store_box(nodes[node].aabb_min, box);
+            if (node == 0)
+                break;
+            child = node;
+            node = nodeParents[node];
+        }
+    }
 }
 
 struct Ws {
     kk_lbvh_ws_layout pub;
-    size_t params, partials, keys1, vals1, blockCounts, arrivals, sortWs;
+    size_t params, partials, keys1, vals1, blockCounts, arrivals, rangeEnds, topList, sortWs;
     size_t sortWsBytes;
     uint32_t headBlocks;
 };
@@ -465,7 +535,9 @@ inline Ws layout(uint32_t N, uint32_t flags) {
     w.pub.node_parents = c.take(4 * n);
     w.pub.leaf_parents = c.take(4 * n);
     w.blockCounts = c.take(4 * static_cast<size_t>(w.headBlocks));
-    w.arrivals = c.take(4 * n);
+    w.arrivals = c.take(4 * n + 4);
+    w.rangeEnds = c.take(4 * n);
+    w.topList = c.take(4 * n);
     w.sortWsBytes = kk_sort_workspace_bytes(N);
     w.sortWs = c.take(w.sortWsBytes);
     // the sort's error word sits right after its histogram and counters (radix_sort.hip: sort_ws)
@@ -516,6 +588,8 @@ extern "C" int kk_lbvh_build(const float *d_positions, uint32_t vert_num,
     auto *leafParents = reinterpret_cast<uint32_t *>(b + w.pub.leaf_parents);
     auto *blockCounts = reinterpret_cast<uint32_t *>(b + w.blockCounts);
     auto *arrivals = reinterpret_cast<uint32_t *>(b + w.arrivals);
+    auto *rangeEnds = reinterpret_cast<uint32_t *>(b + w.rangeEnds);
+    auto *topList = reinterpret_cast<uint32_t *>(b + w.topList);
     const uint32_t N = face_num;
 
     uint32_t bgrid = div_up(vert_num, THREADS);
@@ -552,11 +626,17 @@ extern "C" int kk_lbvh_build(const float *d_positions, uint32_t vert_num,
                                                     d_compacted, d_out, leafAABBs);
     KK_LAUNCH_CHECK();
     karras_links_kernel<<<ngrid, THREADS, 0, stream>>>(uniq, d_out, d_nodes, nodeParents,
-                                                       leafParents);
+                                                       leafParents, rangeEnds);
     KK_LAUNCH_CHECK();
-    KK_HIP_TRY(hipMemsetAsync(arrivals, 0, 4ull * N, stream));
-    refit_kernel<<<ngrid, THREADS, 0, stream>>>(leafAABBs, d_out, d_nodes, nodeParents, leafParents,
-                                                arrivals);
+    // arrivals[0 .. N) are the top-phase counters; the word after them counts the work list
+    KK_HIP_TRY(hipMemsetAsync(arrivals, 0, 4ull * N + 4, stream));
+    uint32_t *topCount = arrivals + N;
+    refit_local_kernel<<<div_up(N, REFIT_LEAVES), THREADS, 0, stream>>>(
+        leafAABBs, d_out, d_nodes, nodeParents, leafParents, rangeEnds, topList, topCount);
+    KK_LAUNCH_CHECK();
+    refit_top_kernel<<<REFIT_TOP_BLOCKS, THREADS, 0, stream>>>(leafAABBs, d_nodes, nodeParents,
+                                                               leafParents, topList, topCount,
+                                                               arrivals);
     KK_LAUNCH_CHECK();
     return KK_OK;
 }
