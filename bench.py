@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot paths on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" is one pass of the closest-hit path over one batch of synthetic input: 2,097,152 incoherent
+rays (seed 0x5EED0002) traced through the LBVH of the 10 M-triangle soup (seed 0x5EED0001); the rays
+and the tree are resident in HBM before the timed region. The same run also times the LBVH build of
+that soup (ms per 10 M triangles) and, when the volume path is built, the DVR frame rate; they are
+reported in the same JSON line beside the headline value.
+
+N > 1 (launched with torch.distributed.run, one rank per GPU): the tree is built once on rank 0 and
+broadcast over RCCL; every rank then traces its own 2 M-ray slice of the ray stream (weak scaling,
+no collective on the data path). Timing is bracketed by barrier + synchronize and the maximum over
+ranks is taken.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from raytracer_amd import synthetic as syn  # noqa: E402
+from raytracer_amd.lbvh import LBVH  # noqa: E402
+from raytracer_amd.ray_tracer import closest_hit  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak
+LBVH_BYTES_PER_TRI = 368  # algorithmic bytes of the build per triangle of a non-indexed soup
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--tris", type=int, default=10_000_000)
+    ap.add_argument("--rays", type=int, default=2_097_152)
+    ap.add_argument("--cpu-rays", type=int, default=262_144, help="rays of the CPU baseline sample")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-dvr", action="store_true")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+        dist = dist_
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device(f"cuda:{local_rank}"))
+    torch.cuda.set_device(local_rank)
+    dev = f"cuda:{local_rank}"
+    N, R, K, W = args.tris, args.rays, args.steps, args.warmup
+
+    # ---- scene: built once (rank 0), broadcast to the others ----------------------------------------
+    bvh = LBVH(dev)
+    build_ms = None
+    pos = tri = None
+    if rank == 0:
+        pos, tri = syn.triangle_soup(N)
+        bvh.BuildFrom(torch.from_numpy(pos), torch.from_numpy(tri.view(np.int32)))
+        assert bvh.IsComplete(), "LBVH build failed"
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        times = []
+        for i in range(3 + 10):
+            ev[0].record()
+            bvh.rebuild()
+            ev[1].record()
+            torch.cuda.synchronize()
+            if i >= 3:
+                times.append(ev[0].elapsed_time(ev[1]))
+        build_ms = float(np.median(times))
+    bcast_ms = None
+    if world > 1:
+        from raytracer_amd.multi_gpu import broadcast_lbvh
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        broadcast_lbvh(bvh, src=0)
+        torch.cuda.synchronize()
+        dist.barrier()
+        bcast_ms = (time.perf_counter() - t0) * 1e3
+    M = bvh.GetDeviceData()["compactedFaceNum"]
+
+    # ---- rays: each rank owns rays [rank*R, (rank+1)*R) of the stream --------------------------------
+    rays_h = syn.incoherent_rays(R, first=rank * R)
+    rays = torch.from_numpy(rays_h).to(dev)
+    l_out = None
+    t, bary, prim, counters = closest_hit(bvh, rays, count=True)
+    torch.cuda.synchronize()
+    from raytracer_amd import _lib
+    ws = torch.empty(_lib.lib().kk_closest_hit_workspace_bytes(), dtype=torch.uint8, device=dev)
+    l_out = (t, bary, prim, ws)
+
+    for _ in range(W):
+        closest_hit(bvh, rays, out=l_out)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(K):
+        closest_hit(bvh, rays, out=l_out)
+    ev1.record()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    wall = time.perf_counter() - t0
+    kernel_ms = ev0.elapsed_time(ev1) / K  # HIP events on the launch stream: average launch duration
+    if dist:
+        tt = torch.tensor([wall], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        wall = float(tt.item())
+    ms_per_step = wall * 1e3 / K
+    value = world * R / (ms_per_step * 1e-3) / 1e6
+
+    if rank != 0:
+        if dist:
+            dist.destroy_process_group()
+        return
+
+    # ---- roofline of the dominant kernel (closest_hit_kernel) ---------------------------------------
+    # algorithmic bytes per launch: 32 B per node box fetched + 48 B per triangle tested (12 B indices
+    # + 36 B vertices) + 24 B ray in + 16 B hit out, counted by the kernel's own work counters
+    alg_bytes = 32 * counters["node_fetches"] + 48 * counters["tri_tests"] + (24 + 16) * R
+    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+    roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                "kernel": "closest_hit_kernel", "avg_launch_ms": round(kernel_ms, 4),
+                "algorithmic_bytes_per_launch": int(alg_bytes),
+                "node_fetches_per_ray": round(counters["node_fetches"] / R, 2),
+                "tri_tests_per_ray": round(counters["tri_tests"] / R, 2)}
+    pmc = os.path.join(ROOT, "profiles", "r01_closest_hit_pmc.json")
+    if os.path.exists(pmc):
+        try:
+            roofline["traffic"] = json.load(open(pmc)).get("hbm_bytes_per_launch")
+        except (OSError, ValueError):
+            pass
+
+    out = {
+        "metric": "Mrays/s closest-hit", "value": round(value, 2), "unit": "Mrays/s",
+        "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "10M-triangle soup LBVH + 2M incoherent closest-hit rays per GPU",
+                   "triangles": N, "leaves": M, "rays_per_gpu": R, "parallelism": f"replicated-bvh x{world}"},
+        "roofline": roofline,
+        "hit_fraction": round(float((prim >= 0).float().mean()), 4),
+    }
+    if build_ms is not None:
+        gbps = LBVH_BYTES_PER_TRI * N / (build_ms * 1e-3) / 1e9
+        out["lbvh_build"] = {"ms": round(build_ms, 4), "ms_per_10Mtri": round(build_ms * 1e7 / N, 4),
+                             "bytes_per_tri": LBVH_BYTES_PER_TRI, "achieved_GBps": round(gbps, 1),
+                             "frac_of_hbm_peak": round(gbps / HBM_PEAK_GBPS, 4)}
+    if bcast_ms is not None:
+        out["lbvh_broadcast_ms"] = round(bcast_ms, 3)
+
+    # ---- CPU baseline: the reference's logic (oracle port) on the host cores, bounded sample --------
+    if world == 1 and not args.no_cpu:
+        from oracle import kkoracle as ko
+        cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or (os.cpu_count() or 1)
+        if pos is None:
+            pos, tri = syn.triangle_soup(N)
+        t0 = time.perf_counter()
+        ref = ko.lbvh_build(pos, tri, refit_mode=1)
+        cpu_build_s = time.perf_counter() - t0
+        S = min(args.cpu_rays, R)
+        t0 = time.perf_counter()
+        rt, rbary, rprim, rstats = ko.closest_hit(ref, pos, tri, rays_h[:S])
+        cpu_trace_s = time.perf_counter() - t0
+        out["cpu_baseline"] = {
+            "value": round(S / cpu_trace_s / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "sample": f"first {S} of the {R} rays through the same 10M-triangle LBVH "
+                      f"(reference traversal order, no distance culling)",
+            "lbvh_build_ms_per_10Mtri": round(cpu_build_s * 1e3 * 1e7 / N, 1),
+            "node_fetches_per_ray": round(rstats["node_fetches"] / S, 1),
+        }
+        # the sample doubles as a full-size parity check
+        gp = prim[:S].cpu().numpy().view(np.uint32)
+        gt = t[:S].cpu().numpy()
+        mism = gp != rprim
+        hit = ~mism & (rprim != 0xFFFFFFFF)
+        rel = np.abs(gt[hit] - rt[hit]) / np.maximum(np.abs(rt[hit]), 1e-30)
+        out["parity_vs_cpu"] = {"rays": int(S), "prim_mismatch_frac": float(mism.mean()),
+                                "max_rel_t_err": float(rel.max()) if rel.size else 0.0,
+                                "tree_bit_exact": bool(
+                                    ref["M"] == M and
+                                    np.array_equal(bvh.d_faces.cpu().numpy().view(np.uint32), ref["faces"]) and
+                                    bvh.d_nodes[:(M - 1) * 32].cpu().numpy().tobytes() ==
+                                    ref["internalNodes"].tobytes())}
+
+    # ---- volume path (reported beside the headline value) -------------------------------------------
+    if not args.no_dvr:
+        try:
+            from raytracer_amd import bench_dvr
+            out["dvr"] = bench_dvr.run(dev, world, rank)
+        except ImportError:
+            pass
+
+    print(json.dumps(out))
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

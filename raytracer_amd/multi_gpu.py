@@ -1,0 +1,72 @@
+"""One process per GPU: a structure built once on one rank is broadcast to the others over RCCL
+(torch.distributed, backend "nccl"), the image or ray buffer is split between ranks, and per-rank
+tiles are gathered to rank 0. Nothing here is on the per-ray data path: there is one broadcast at
+set-up and one gather per frame.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import _lib
+from .lbvh import LBVH
+
+
+def _bcast_meta(values, src, device):
+    t = torch.tensor(values, dtype=torch.float64, device=device)
+    dist.broadcast(t, src=src)
+    return t.cpu().tolist()
+
+
+def write_lbvh_device_data(bvh: LBVH, root_aabb, face_num: int, compacted_num: int) -> None:
+    """Rebuilds the 64-byte DeviceData of a received tree: device pointers are local to each rank."""
+    dd = _lib.LbvhDeviceData()
+    for k in range(3):
+        dd.root_aabb_min[k] = float(root_aabb[k])
+        dd.root_aabb_max[k] = float(root_aabb[3 + k])
+    dd.face_num, dd.compacted_face_num = face_num, compacted_num
+    dd.faces, dd.compacted_faces = bvh.d_faces.data_ptr(), bvh.d_compacted.data_ptr()
+    dd.internal_nodes = bvh.d_nodes.data_ptr()
+    raw = np.frombuffer(bytes(dd), dtype=np.uint8).copy()
+    bvh.d_device_data = torch.from_numpy(raw).to(bvh.device)
+    bvh._host_dd = None
+
+
+def broadcast_lbvh(bvh: LBVH, src: int = 0) -> None:
+    """Broadcasts the built tree and the mesh it indexes: faces (4N B), compactedFaces (4M),
+    internalNodes (32(M-1)), positions (12V), triangle indices (12N)."""
+    rank = dist.get_rank()
+    dev = bvh.device
+    if rank == src:
+        dd = bvh.GetDeviceData()
+        meta = [dd["faceNum"], bvh.d_positions.shape[0], dd["compactedFaceNum"]] + \
+            [float(x) for x in dd["rootAABB"]]
+    else:
+        meta = [0.0] * 9
+    meta = _bcast_meta(meta, src, dev)
+    N, V, M = int(meta[0]), int(meta[1]), int(meta[2])
+    root = np.array(meta[3:9], dtype=np.float64).astype(np.float32)
+    if rank != src:
+        bvh.face_num = N
+        bvh.d_positions = torch.empty((V, 3), dtype=torch.float32, device=dev)
+        bvh.d_face_pos_idx = torch.empty((N, 3), dtype=torch.int32, device=dev)
+        bvh.d_faces = torch.empty(N, dtype=torch.int32, device=dev)
+        bvh.d_compacted = torch.empty(N, dtype=torch.int32, device=dev)
+        bvh.d_nodes = torch.empty(N * 32, dtype=torch.uint8, device=dev)
+    nodes_used = max(M - 1, 1) * 32
+    for t in (bvh.d_positions, bvh.d_face_pos_idx, bvh.d_faces, bvh.d_compacted[:M],
+              bvh.d_nodes[:nodes_used]):
+        dist.broadcast(t, src=src)
+    if rank != src:
+        write_lbvh_device_data(bvh, root, N, M)
+        bvh._complete = True
+
+
+def split_range(total: int, world: int, rank: int):
+    """Contiguous share [begin, end) of `total` items for `rank`."""
+    base, rem = divmod(total, world)
+    begin = rank * base + min(rank, rem)
+    return begin, begin + base + (1 if rank < rem else 0)
