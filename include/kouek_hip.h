@@ -138,6 +138,85 @@ int kk_closest_hit(const kk_lbvh_device_data *d_lbvh, const float *d_positions,
                    float *d_bary, uint32_t *d_prim, int mode, unsigned long long *d_counters,
                    void *d_workspace, size_t workspace_bytes, void *stream);
 
+/* ================================================================================================
+ * Path 1c: path tracer  --  kouek::RayTracer::RayTracer::Render(surface, size, RenderTarget::Scene)
+ *          (src/ray_tracer/ray_tracer_render.cu:433-647; setters in src/ray_tracer/ray_tracer.cu)
+ * ============================================================================================== */
+
+/* include/ray_tracer/ray_tracer.h:29-33 (16-byte aligned: 32 bytes) */
+typedef struct kk_pt_triangle {
+    uint32_t norm_idx[3];
+    uint32_t tex_coord_idx[3];
+    uint32_t grp_idx;
+    uint32_t _pad;
+} kk_pt_triangle;
+
+/* include/ray_tracer/material.h:12-22, same offsets (64 bytes) */
+typedef struct kk_material {
+    uint8_t emissive;
+    uint8_t _pad[3];
+    float emission[3], kd[3], ks[3], tr[3];
+    float ni, ns, kd_over_kd_add_ks;
+} kk_material;
+
+/* include/ray_tracer/material.h:51-66, same offsets (80 bytes). type: 0 = quad, 1 = sphere */
+typedef struct kk_light {
+    uint8_t type;
+    uint8_t _pad[3];
+    union {
+        struct {
+            float o[3], u[3], v[3], n[3];
+            float inv_area;
+        } quad;
+        struct {
+            float o[3];
+            float r, r_sqr;
+        } sphere;
+    };
+    float area;
+    float radiance[3];
+    float _pad2[2];
+} kk_light;
+
+/* The fields of RayTracer::RenderParameter (ray_tracer.h:34-49) the Scene target reads; a host struct
+ * passed by value to the kernel. Matrices are column-major (glm). Pointers are device pointers. */
+typedef struct kk_pt_scene {
+    uint8_t display_tree_height;
+    uint8_t max_path_depth;
+    uint8_t _pad[2];
+    uint32_t light_num;
+    float w2s[16];
+    float inv_proj[16];
+    const kk_pt_triangle *triangles;
+    const uint32_t *tri_to_position_indices; /* uint32[N][3] */
+    const float *positions;                  /* float[V][3] */
+    const float *normals;                    /* float[.][3] */
+    const float *tex_coords;                 /* float[.][2], unused by the Scene target */
+    const kk_light *lights;
+    const kk_material *materials;
+    float light_tot_area;
+    uint32_t _pad2;
+} kk_pt_scene;
+
+/* RayTracer::RenderParameterPerFrame (ray_tracer.h:50-53); eye_rot column-major mat3 */
+typedef struct kk_pt_frame {
+    float eye_pos[3];
+    float eye_rot[9];
+} kk_pt_frame;
+
+/* One Render(Scene) call restricted to pixel rows [y0, y1) (row 0 = bottom row, as in the reference's
+ * GL surface): adds sample number `sample_index` (the reference's currAccuSamplePerPixel, 1-based) to
+ * the running mean d_accum float[H][W][3] and writes d_rgba uint8[H][W][4] (alpha 255). The caller
+ * zeroes d_accum when accumulation restarts (ray_tracer_render.cu:561-574). A pixel's random stream
+ * depends only on (seed, y*W+x, sample_index), so any split of the rows gives the same image. */
+int kk_pt_render_sample(const kk_lbvh_device_data *d_lbvh, const kk_pt_scene *h_scene,
+                        const kk_pt_frame *h_frame, float *d_accum, uint8_t *d_rgba, int width,
+                        int height, int y0, int y1, float sample_index, uint32_t seed, void *stream);
+
+/* The first `count` uniforms in (0, 1] of the stream (seed, pixel, sample), for checking the generator. */
+int kk_rng_uniforms(uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t count, float *d_out,
+                    void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -159,3 +159,53 @@ def hit_aabb(ray6, aabb6, which="oracle"):
     l = lib() if which == "oracle" else ref()
     f = l.ko_hit_aabb if which == "oracle" else l.kkref_hit_aabb
     return _call(f, np.ascontiguousarray(ray6, np.float32), np.ascontiguousarray(aabb6, np.float32), out)
+
+
+# ---- path tracer ---------------------------------------------------------------------------------------
+
+class _KoPtScene(C.Structure):
+    _fields_ = [("inodes", C.c_void_p), ("faces", C.c_void_p), ("compactedFaces", C.c_void_p),
+                ("faceNum", C.c_uint32), ("compactedFaceNum", C.c_uint32), ("positions", C.c_void_p),
+                ("facePosIdx", C.c_void_p), ("normals", C.c_void_p), ("triangles", C.c_void_p),
+                ("materials", C.c_void_p), ("lights", C.c_void_p), ("lightNum", C.c_uint32),
+                ("lightTotArea", C.c_float), ("maxPathDepth", C.c_uint32), ("w2s", C.c_float * 16),
+                ("invProj", C.c_float * 16), ("eyePos", C.c_float * 3), ("eyeRot", C.c_float * 9)]
+
+
+def pt_render_sample(bvh: dict, arrays: dict, w2s, inv_proj, eye_pos, eye_rot, accum: np.ndarray,
+                     rgba: np.ndarray, sample_idx: float, seed: int = 1234, max_path_depth: int = 4,
+                     rows=None) -> None:
+    """One Render(Scene) call on the CPU. arrays: triangles / tri / positions / normals / lights /
+    materials as numpy arrays in the reference's struct layouts. accum [H,W,3] f32 and rgba [H,W,4]
+    u8 are updated in place."""
+    H, W = accum.shape[:2]
+    sc = _KoPtScene()
+    keep = {k: np.ascontiguousarray(v) for k, v in arrays.items()}
+    sc.inodes, sc.faces = _vp(bvh["internalNodes"]).value, _vp(bvh["faces"]).value
+    sc.compactedFaces = _vp(bvh["compactedFaces"]).value
+    sc.faceNum, sc.compactedFaceNum = bvh["N"], bvh["M"]
+    sc.positions, sc.facePosIdx = _vp(keep["positions"]).value, _vp(keep["tri"]).value
+    sc.normals, sc.triangles = _vp(keep["normals"]).value, _vp(keep["triangles"]).value
+    sc.materials = _vp(keep["materials"]).value
+    sc.lights = _vp(keep["lights"]).value if keep["lights"].size else None
+    sc.lightNum = int(keep["lights"].size)
+    tot = np.float32(0)
+    for a in keep["lights"]["area"]:
+        tot = np.float32(tot + a)
+    sc.lightTotArea = float(tot)
+    sc.maxPathDepth = max_path_depth
+    for name, val in (("w2s", w2s), ("invProj", inv_proj), ("eyePos", eye_pos), ("eyeRot", eye_rot)):
+        arr = getattr(sc, name)
+        for i, x in enumerate(np.asarray(val, np.float32).reshape(-1)):
+            arr[i] = float(x)
+    y0, y1 = rows if rows is not None else (0, H)
+    assert accum.flags.c_contiguous and rgba.flags.c_contiguous
+    lib().ko_pt_render_sample(C.byref(sc), _vp(accum), _vp(rgba), C.c_int(W), C.c_int(H), C.c_int(y0),
+                              C.c_int(y1), C.c_float(sample_idx), C.c_uint32(seed))
+
+
+def rng_uniforms(seed: int, pixel: int, sample: int, count: int) -> np.ndarray:
+    out = np.zeros(count, np.float32)
+    lib().ko_rng_uniforms(C.c_uint32(seed), C.c_uint32(pixel), C.c_uint32(sample), C.c_uint32(count),
+                          _vp(out))
+    return out

@@ -53,6 +53,8 @@ def _declare(l):
     l.kk_lbvh_build.argtypes = [vp, u32, vp, u32, vp, vp, vp, vp, vp, sz, u32, vp]
     l.kk_closest_hit_workspace_bytes.restype = sz
     l.kk_closest_hit.argtypes = [vp, vp, vp, vp, u32, vp, vp, vp, i32, vp, vp, sz, vp]
+    l.kk_pt_render_sample.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, C.c_float, u32, vp]
+    l.kk_rng_uniforms.argtypes = [u32, u32, u32, u32, vp, vp]
     for name in ("kk_malloc", "kk_free", "kk_memcpy_h2d", "kk_memcpy_d2h", "kk_memset",
                  "kk_stream_synchronize", "kk_set_device"):
         getattr(l, name).restype = i32

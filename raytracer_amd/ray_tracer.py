@@ -2,6 +2,8 @@
 (include/ray_tracer/ray_tracer.h:23-136)."""
 from __future__ import annotations
 
+import ctypes as C
+
 import numpy as np
 import torch
 
@@ -38,3 +40,231 @@ def closest_hit(lbvh: LBVH, rays, count: bool = False, out=None):
         c = counters.cpu().numpy()
         return t, bary, prim, {"node_fetches": int(c[0]), "tri_tests": int(c[1]), "rays": int(c[2])}
     return t, bary, prim
+
+
+# ---- materials / lights as the reference lays them out ------------------------------------------------
+
+TRIANGLE_DTYPE = np.dtype([("normIdx", "<u4", (3,)), ("texCoordIdx", "<u4", (3,)), ("grpIdx", "<u4"),
+                           ("_pad", "<u4")])
+MATERIAL_DTYPE = np.dtype([("emissive", "u1"), ("_pad", "u1", (3,)), ("emission", "<f4", (3,)),
+                           ("kd", "<f4", (3,)), ("ks", "<f4", (3,)), ("tr", "<f4", (3,)),
+                           ("ni", "<f4"), ("ns", "<f4"), ("kdOverKdAddKs", "<f4")])
+# union at offset 4: quad {o,u,v,n,invArea} / sphere {o,r,rSqr}
+LIGHT_DTYPE = np.dtype({"names": ["type", "quad_o", "quad_u", "quad_v", "quad_n", "quad_invArea",
+                                  "sphere_o", "sphere_r", "sphere_rSqr", "area", "radiance"],
+                        "formats": ["u1", ("<f4", (3,)), ("<f4", (3,)), ("<f4", (3,)), ("<f4", (3,)),
+                                    "<f4", ("<f4", (3,)), "<f4", "<f4", "<f4", ("<f4", (3,))],
+                        "offsets": [0, 4, 16, 28, 40, 52, 4, 16, 20, 56, 60], "itemsize": 80})
+assert TRIANGLE_DTYPE.itemsize == 32 and MATERIAL_DTYPE.itemsize == 64 and LIGHT_DTYPE.itemsize == 80
+
+f32 = np.float32
+
+
+def create_material(kd, ks, tr, ni, ns, emission=(0, 0, 0)) -> np.ndarray:
+    """Material::Create (include/ray_tracer/material.h:23-39)."""
+    m = np.zeros((), MATERIAL_DTYPE)
+    kd, ks, emission = np.asarray(kd, f32), np.asarray(ks, f32), np.asarray(emission, f32)
+    m["emissive"] = bool((emission != 0).any())
+    m["emission"], m["kd"], m["ks"], m["tr"] = emission, kd, ks, np.asarray(tr, f32)
+    m["ns"], m["ni"] = f32(ns), f32(ni)
+    kd_avg = f32(f32(f32(kd[0] + kd[1]) + kd[2]) / f32(3))
+    ks_avg = f32(f32(f32(ks[0] + ks[1]) + ks[2]) / f32(3))
+    with np.errstate(invalid="ignore", divide="ignore"):
+        m["kdOverKdAddKs"] = f32(kd_avg / f32(kd_avg + ks_avg))
+    return m
+
+
+def create_sphere_light(r, o, radiance) -> np.ndarray:
+    """Light::CreateSphere (material.h:82-93): area = 2 * two_pi * r^2."""
+    l = np.zeros((), LIGHT_DTYPE)
+    r = f32(r)
+    l["type"] = 1
+    l["sphere_o"], l["sphere_r"], l["sphere_rSqr"] = np.asarray(o, f32), r, f32(r * r)
+    l["area"] = f32(f32(f32(2) * f32(6.28318530717958647692528676655900576)) * f32(r * r))
+    l["radiance"] = np.asarray(radiance, f32)
+    return l
+
+
+def create_quad_light(o, u, v, radiance) -> np.ndarray:
+    """Light::CreateQuad (material.h:68-81)."""
+    from .data.camera import _cross, _normalize, _dot, _c
+    l = np.zeros((), LIGHT_DTYPE)
+    o, u, v = np.asarray(o, f32), np.asarray(u, f32), np.asarray(v, f32)
+    l["type"] = 0
+    l["quad_o"], l["quad_u"], l["quad_v"] = o, u, v
+    l["quad_n"] = _normalize(_cross(u, v))
+    area = f32(_c("sqrtf", _dot(u, u)) * _c("sqrtf", _dot(v, v)))
+    l["area"] = area
+    l["quad_invArea"] = f32(f32(1) / area)
+    l["radiance"] = np.asarray(radiance, f32)
+    return l
+
+
+def stack_structs(items, dtype) -> np.ndarray:
+    """Array of structs from a list of 0-d struct values, keeping `dtype`'s explicit offsets
+    (np.array() of such a list would repack the fields)."""
+    out = np.zeros(len(items), dtype)
+    for i, it in enumerate(items):
+        out[i] = it
+    return out
+
+
+class _PtScene(C.Structure):
+    _fields_ = [("display_tree_height", C.c_uint8), ("max_path_depth", C.c_uint8),
+                ("_pad", C.c_uint8 * 2), ("light_num", C.c_uint32), ("w2s", C.c_float * 16),
+                ("inv_proj", C.c_float * 16), ("triangles", C.c_void_p),
+                ("tri_to_position_indices", C.c_void_p), ("positions", C.c_void_p),
+                ("normals", C.c_void_p), ("tex_coords", C.c_void_p), ("lights", C.c_void_p),
+                ("materials", C.c_void_p), ("light_tot_area", C.c_float), ("_pad2", C.c_uint32)]
+
+
+class _PtFrame(C.Structure):
+    _fields_ = [("eye_pos", C.c_float * 3), ("eye_rot", C.c_float * 9)]
+
+
+class FrameBuffer:
+    """Headless stand-in for the GL surface the reference renders into: RGBA8, row 0 = bottom row."""
+
+    def __init__(self, width: int, height: int, device="cuda:0"):
+        self.width, self.height = int(width), int(height)
+        self.rgba = torch.zeros((self.height, self.width, 4), dtype=torch.uint8, device=device)
+
+    def ReadBack(self) -> np.ndarray:
+        return self.rgba.cpu().numpy()
+
+
+class RayTracer:
+    """kouek::RayTracer::RayTracer (include/ray_tracer/ray_tracer.h:23-136): setters with the
+    reference's restart-on-change behaviour, Render(framebuffer) adds one sample per call."""
+    ErrTag = "[RayTracer Error]"
+    SEED = 1234  # curand_init(1234, pixel, 0), ray_tracer_render.cu:572
+
+    def __init__(self, device="cuda:0"):
+        self.device = torch.device(device)
+        self.lbvh = None
+        self.max_sample_per_pixel = 1024.0
+        self._prev_max_spp = 1024.0
+        self.curr_accu_spp = 0.0
+        self._prev_size = (0, 0)
+        self._prev_fb = None
+        self._modified = True
+        self._scene = _PtScene()
+        self._scene.max_path_depth = 4
+        self._frame = _PtFrame()
+        self.d_accum = None
+        self._keep = {}
+
+    # -- setters (ray_tracer.cu:15-107); any change restarts accumulation at the next Render ----------
+    def _set(self, obj, name, value):
+        cur = getattr(obj, name)
+        if hasattr(cur, "__len__"):
+            new = [float(x) for x in np.asarray(value, np.float32).reshape(-1)]
+            if list(cur) != new:
+                for i, x in enumerate(new):
+                    cur[i] = x
+                self._modified = True
+        elif cur != value:
+            setattr(obj, name, value)
+            self._modified = True
+
+    def SetMesh(self, positions, normals, tex_coords, group_start_face_indices, face_position_indices,
+                face_normal_indices, face_tex_coord_indices, lights, materials):
+        dev = self.device
+        fpi = np.ascontiguousarray(face_position_indices, np.uint32).reshape(-1, 3)
+        n = fpi.shape[0]
+        tris = np.zeros(n, TRIANGLE_DTYPE)
+        tris["normIdx"] = np.asarray(face_normal_indices, np.uint32).reshape(-1, 3)
+        tris["texCoordIdx"] = np.asarray(face_tex_coord_indices, np.uint32).reshape(-1, 3)
+        # group of a face: last group whose start is <= the face (ray_tracer.cu:43-57)
+        gs = np.asarray(group_start_face_indices, np.uint32)
+        tris["grpIdx"] = (np.searchsorted(gs[1:], np.arange(n, dtype=np.uint32), side="right")
+                          if gs.size > 1 else 0)
+        lights = lights if isinstance(lights, np.ndarray) else stack_structs(lights, LIGHT_DTYPE)
+        materials = (materials if isinstance(materials, np.ndarray)
+                     else stack_structs(materials, MATERIAL_DTYPE))
+        assert lights.dtype.itemsize == 80 and materials.dtype.itemsize == 64, "struct layout lost"
+
+        def up(a, dtype=None):
+            a = np.ascontiguousarray(a)
+            return torch.from_numpy(a.view(np.uint8).reshape(-1).copy()).to(dev)
+
+        k = self._keep
+        k["triangles"], k["tri"] = up(tris), up(fpi)
+        k["positions"] = up(np.asarray(positions, np.float32))
+        k["normals"] = up(np.asarray(normals, np.float32))
+        k["tex_coords"] = up(np.asarray(tex_coords, np.float32)) if len(tex_coords) else up(np.zeros(2, np.float32))
+        k["lights"] = up(lights) if lights.size else None
+        k["materials"] = up(materials)
+        s = self._scene
+        s.triangles, s.tri_to_position_indices = k["triangles"].data_ptr(), k["tri"].data_ptr()
+        s.positions, s.normals = k["positions"].data_ptr(), k["normals"].data_ptr()
+        s.tex_coords, s.materials = k["tex_coords"].data_ptr(), k["materials"].data_ptr()
+        s.lights = k["lights"].data_ptr() if lights.size else None
+        s.light_num = int(lights.size)
+        tot = np.float32(0)
+        for a in lights["area"]:
+            tot = np.float32(tot + a)
+        s.light_tot_area = float(tot)
+        self.host_arrays = {"triangles": tris, "tri": fpi, "positions": np.asarray(positions, np.float32),
+                            "normals": np.asarray(normals, np.float32), "lights": lights,
+                            "materials": materials}
+        self._modified = True
+
+    def SetLBVH(self, lbvh: LBVH):
+        self.lbvh = lbvh
+
+    def SetWorldToScene(self, w2s):
+        self._set(self._scene, "w2s", w2s)
+
+    def SetCameraToWorld(self, eye_pos, eye_rot):
+        self._set(self._frame, "eye_pos", eye_pos)
+        self._set(self._frame, "eye_rot", eye_rot)
+
+    def SetProjection(self, proj):
+        from .data.camera import inverse_projective
+        self._set(self._scene, "inv_proj", inverse_projective(proj))
+
+    def SetDisplayTreeHeight(self, h: int):
+        self._set(self._scene, "display_tree_height", int(h))
+
+    def SetMaxPathDepth(self, d: int):
+        self._set(self._scene, "max_path_depth", int(d))
+
+    def SetMaxSamplePerPixel(self, v: float):
+        self.max_sample_per_pixel = float(v)
+
+    def GetMaxSamplePerPixel(self) -> float:
+        return self.max_sample_per_pixel
+
+    def GetCurrentAccumulatedSamplePerPixel(self) -> float:
+        return self.curr_accu_spp
+
+    def Render(self, fb: FrameBuffer, rows=None) -> None:
+        """ray_tracer_render.cu:433-647 for RenderTarget::Scene. `rows` = (y0, y1) restricts the call
+        to a stripe of the image (multi-GPU tiling); the sample counter advances all the same."""
+        import sys
+        if self.lbvh is None or not self.lbvh.IsComplete():
+            print(f"{self.ErrTag} lbvh is not set.", file=sys.stderr)
+            return
+        size = (fb.width, fb.height)
+        need_redraw = self._modified
+        self._modified = False
+        if self._prev_size != size or self.d_accum is None:
+            self.d_accum = torch.zeros((fb.height, fb.width, 3), dtype=torch.float32, device=self.device)
+        need_redraw |= (self._prev_max_spp != self.max_sample_per_pixel or self._prev_fb is not fb or
+                        self._prev_size != size)
+        if need_redraw:
+            self.curr_accu_spp = 1.0
+            self.d_accum.zero_()
+        self._prev_fb, self._prev_size = fb, size
+        if self.curr_accu_spp > self.max_sample_per_pixel:
+            return
+        y0, y1 = rows if rows is not None else (0, fb.height)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().kk_pt_render_sample(
+                self.lbvh.GetDeivceDataDevicePtr(), C.byref(self._scene), C.byref(self._frame),
+                self.d_accum.data_ptr(), fb.rgba.data_ptr(), fb.width, fb.height, int(y0), int(y1),
+                C.c_float(self.curr_accu_spp), self.SEED, _lib.current_stream_ptr()),
+                "kk_pt_render_sample")
+        self._prev_max_spp = self.max_sample_per_pixel
+        self.curr_accu_spp += 1.0

@@ -1,0 +1,114 @@
+"""Path-tracing frame on the GPU against the CPU checker: same generator values, radiance within 1e-3
+absolute (the two sides differ only in libm vs device transcendental rounding, which can flip a rare
+shadow or lobe decision)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+from raytracer_amd import _lib  # noqa: E402
+from raytracer_amd.data import camera as cam  # noqa: E402
+from raytracer_amd.lbvh import LBVH  # noqa: E402
+from raytracer_amd.ray_tracer import FrameBuffer, RayTracer  # noqa: E402
+from scene_util import veach_arrays, veach_camera  # noqa: E402
+
+DEV = "cuda:0"
+TOL = 1e-3
+
+
+def test_generator_matches_checker(oracle):
+    out = torch.zeros(64, dtype=torch.float32, device=DEV)
+    for seed, pixel, sample in [(1234, 0, 1), (1234, 123456, 7), (99, 2 ** 31 + 5, 1024)]:
+        _lib.check(_lib.lib().kk_rng_uniforms(seed, pixel, sample, 64, out.data_ptr(), None), "rng")
+        torch.cuda.synchronize()
+        assert out.cpu().numpy().tobytes() == oracle.rng_uniforms(seed, pixel, sample, 64).tobytes()
+
+
+def _setup(veach, W, H):
+    arr = veach_arrays(veach)
+    bvh = LBVH(DEV)
+    bvh.BuildFrom(veach["positions"], veach["face_position_indices"])
+    assert bvh.IsComplete()
+    tracer = RayTracer(DEV)
+    tracer.SetWorldToScene(np.eye(4, dtype=np.float32))
+    tracer.SetMesh(veach["positions"], veach["normals"], veach["tex_coords"],
+                   veach["grp_start_face_indices"], veach["face_position_indices"],
+                   veach["face_normal_indices"], veach["face_tex_coord_indices"], arr["lights"],
+                   arr["materials"])
+    tracer.SetLBVH(bvh)
+    tracer.SetMaxPathDepth(4)
+    c, proj = veach_camera(veach, W, H)
+    tracer.SetProjection(proj)
+    tracer.SetCameraToWorld(c.pos, c.rotation())
+    return tracer, arr, c, proj
+
+
+def _oracle_render(oracle, veach, arr, c, proj, W, H, spp):
+    b = oracle.lbvh_build(veach["positions"], veach["face_position_indices"])
+    acc = np.zeros((H, W, 3), np.float32)
+    img = np.zeros((H, W, 4), np.uint8)
+    for s in range(1, spp + 1):
+        oracle.pt_render_sample(b, arr, np.eye(4, dtype=np.float32), cam.inverse_projective(proj),
+                                c.pos, c.rotation(), acc, img, float(s))
+    return acc, img
+
+
+@pytest.mark.parametrize("W,H,spp", [(128, 96, 1), (200, 120, 4)])
+def test_radiance_matches_checker(oracle, veach, W, H, spp):
+    tracer, arr, c, proj = _setup(veach, W, H)
+    fb = FrameBuffer(W, H, DEV)
+    for _ in range(spp):
+        tracer.Render(fb)
+    torch.cuda.synchronize()
+    assert tracer.GetCurrentAccumulatedSamplePerPixel() == spp + 1
+    got = tracer.d_accum.cpu().numpy()
+    ref, ref_img = _oracle_render(oracle, veach, arr, c, proj, W, H, spp)
+    err = np.abs(got - ref).max(axis=2)
+    frac_bad = float((err > TOL).mean())
+    assert frac_bad <= 2e-3, f"{frac_bad:.5f} of the pixels differ by more than {TOL}"
+    assert float(np.abs(got - ref).mean()) < 1e-4
+    img = fb.ReadBack()
+    assert (img[..., 3] == 255).all()
+    assert float((np.abs(img.astype(int) - ref_img.astype(int)).max(axis=2) > 1).mean()) <= 2e-3
+
+
+def test_row_split_gives_the_same_image(veach):
+    W, H = 160, 100
+    tracer, arr, c, proj = _setup(veach, W, H)
+    fb = FrameBuffer(W, H, DEV)
+    tracer.Render(fb)
+    tracer.Render(fb)
+    torch.cuda.synchronize()
+    whole = tracer.d_accum.cpu().numpy().copy()
+    tracer2, *_ = _setup(veach, W, H)
+    fb2 = FrameBuffer(W, H, DEV)
+    for _ in range(2):
+        # both stripes of one sample, then the counter moves on once
+        spp = tracer2.curr_accu_spp
+        tracer2.Render(fb2, rows=(0, 37))
+        tracer2.curr_accu_spp = max(spp, 1.0)
+        tracer2._modified = False
+        tracer2.Render(fb2, rows=(37, H))
+    torch.cuda.synchronize()
+    assert tracer2.d_accum.cpu().numpy().tobytes() == whole.tobytes()
+    assert fb2.ReadBack().tobytes() == fb.ReadBack().tobytes()
+
+
+def test_accumulation_restarts_on_change_and_stops_at_max(veach):
+    W, H = 64, 48
+    tracer, arr, c, proj = _setup(veach, W, H)
+    fb = FrameBuffer(W, H, DEV)
+    tracer.SetMaxSamplePerPixel(3.0)
+    for _ in range(6):
+        tracer.Render(fb)
+    assert tracer.GetCurrentAccumulatedSamplePerPixel() == 4.0  # no-op once above the maximum
+    tracer.SetMaxPathDepth(2)  # a parameter change restarts accumulation (ray_tracer_render.cu:561-574)
+    tracer.Render(fb)
+    assert tracer.GetCurrentAccumulatedSamplePerPixel() == 2.0
+
+
+def test_render_without_lbvh_reports_and_returns(veach, capsys):
+    tracer = RayTracer(DEV)
+    tracer.Render(FrameBuffer(8, 8, DEV))
+    assert "lbvh is not set" in capsys.readouterr().err
