@@ -217,6 +217,132 @@ int kk_pt_render_sample(const kk_lbvh_device_data *d_lbvh, const kk_pt_scene *h_
 int kk_rng_uniforms(uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t count, float *d_out,
                     void *stream);
 
+/* ================================================================================================
+ * Path 2a: Depth-Box VDB build  --  kouek::RayCaster::DepthBoxVDB::BuildFrom<T>
+ *          (src/ray_caster/dpbx_vdb.cu:275-610, updateAtlas :117-273), T = uint8_t or uint16_t
+ * ============================================================================================== */
+
+#define KK_VDB_MAX_LEVEL_NUM 3
+#define KK_VDB_UNDEF_RLT_IDX 0xFFFFFFFFu
+
+/* include/ray_caster/dpbx_vdb.h:39-54, same offsets (128 bytes) */
+typedef struct kk_vdb_param {
+    uint8_t root_lev;
+    uint8_t apron_wid;
+    uint8_t apron_dep_wid;
+    uint8_t log2_dims[KK_VDB_MAX_LEVEL_NUM];
+    int32_t dims[KK_VDB_MAX_LEVEL_NUM];
+    int32_t vox_per_atlas_brick;
+    int32_t min_dep_pos_val_in_brick;
+    int32_t max_dep_pos_val_in_brick;
+    int32_t atlas_brick_per_vdb[3];
+    uint64_t node_starts[KK_VDB_MAX_LEVEL_NUM];
+    uint64_t child_starts[KK_VDB_MAX_LEVEL_NUM];
+    float voxs_per_child[KK_VDB_MAX_LEVEL_NUM];
+    float vox_per_vdb;
+    float vox_per_vol[3];
+    uint32_t _pad;
+} kk_vdb_param;
+
+/* include/ray_caster/dpbx_vdb.h:55-59 (32 bytes) */
+typedef struct kk_vdb_node {
+    int32_t pos[3];                /* first voxel of the node in the volume */
+    int32_t brick_pos_in_atlas[3]; /* leaves only */
+    uint64_t child_pool_offs_relative;
+} kk_vdb_node;
+
+/* Counterpart of DepthBoxVDB::DeviceData (dpbx_vdb.h:60-67), same size (176 bytes). The three CUDA
+ * surface / texture handles are replaced by the atlas in linear memory, stored brick by brick: brick k
+ * belongs to leaf node k and holds vox_per_atlas_brick^3 voxels, x fastest. */
+typedef struct kk_vdb_device_data {
+    kk_vdb_node *node_pools;
+    uint32_t *child_pools;
+    uint32_t *atlas_brick_to_node_indices;
+    void *atlas;
+    uint64_t leaf_num;
+    uint64_t voxel_bytes; /* 1 or 2 */
+    kk_vdb_param vdb_param;
+} kk_vdb_device_data;
+
+/* Sizes the host wiring step (kk_vdb_plan) reports. */
+typedef struct kk_vdb_plan {
+    kk_vdb_param param;
+    uint32_t leaf_slots[3]; /* bricks per axis covering the volume */
+    uint32_t leaf_num;      /* valid (non-empty) leaves */
+    uint64_t node_num;      /* entries of node_pools (root last) */
+    uint64_t child_num;     /* entries of child_pools */
+    uint64_t atlas_map_num; /* entries of atlas_brick_to_node_indices */
+    uint64_t atlas_voxels;  /* leaf_num * vox_per_atlas_brick^3 */
+} kk_vdb_plan;
+
+/* Step 1 (device): d_leaf_valid[z*ly*lx + y*lx + x] = 0 when every voxel of the brick (voxels outside
+ * the volume read 0) lies in an empty scalar range, else 1 (dpbx_vdb.cu:345-385; like the reference it
+ * counts (voxel, range) pairs). d_volume is T[dz][dy][dx], x fastest. h_empty_rngs: n_rngs pairs of T. */
+int kk_vdb_classify_u8(const uint8_t *d_volume, uint32_t dx, uint32_t dy, uint32_t dz,
+                       uint32_t log2_dim0, const uint8_t *h_empty_rngs, uint32_t n_rngs,
+                       uint32_t *d_leaf_valid, void *stream);
+int kk_vdb_classify_u16(const uint16_t *d_volume, uint32_t dx, uint32_t dy, uint32_t dz,
+                        uint32_t log2_dim0, const uint16_t *h_empty_rngs, uint32_t n_rngs,
+                        uint32_t *d_leaf_valid, void *stream);
+
+/* Step 2 (host only, no GPU call): parameters and pool sizes from the validity flags
+ * (dpbx_vdb.cu:282-338, 387-467). Fails like the reference when a log2 dimension is outside [1, 10] or
+ * three levels cannot cover the volume, and also when one brick covers the whole volume or no leaf is
+ * valid (the reference then builds a tree its own marcher cannot walk). */
+int kk_vdb_plan_build(uint32_t dx, uint32_t dy, uint32_t dz, const uint8_t log2_dims[3],
+                      uint8_t apron_wid, int use_depth_box, const uint32_t *h_leaf_valid,
+                      kk_vdb_plan *out);
+/* Step 3 (host only): fills node pools (sorted by level, then x, y, z; root last), dense child pools
+ * (index (z << 2L) | (y << L) | x, undefined = 0xFFFFFFFF) and the atlas map (dpbx_vdb.cu:57-115,
+ * 404-445, 524-571) into caller-allocated host arrays of the planned sizes. */
+int kk_vdb_wire(const kk_vdb_plan *plan, const uint32_t *h_leaf_valid, kk_vdb_node *h_node_pools,
+                uint32_t *h_child_pools, uint32_t *h_atlas_brick_to_node);
+
+/* Step 4 (device): fills the brick-major atlas for the plan's leaves (dpbx_vdb.cu:176-272): volume
+ * voxels for the brick and its apron, depth values on the one-face shell voxels, 0 on shell edges. */
+int kk_vdb_fill_atlas_u8(const uint8_t *d_volume, uint32_t dx, uint32_t dy, uint32_t dz,
+                         const kk_vdb_plan *plan, const kk_vdb_node *d_node_pools,
+                         const uint8_t *h_empty_rngs, uint32_t n_rngs, uint8_t *d_atlas, void *stream);
+int kk_vdb_fill_atlas_u16(const uint16_t *d_volume, uint32_t dx, uint32_t dy, uint32_t dz,
+                          const kk_vdb_plan *plan, const kk_vdb_node *d_node_pools,
+                          const uint16_t *h_empty_rngs, uint32_t n_rngs, uint16_t *d_atlas,
+                          void *stream);
+
+/* ================================================================================================
+ * Path 2b: DVR marcher  --  kouek::RayCaster::RayCaster::RenderDepthBoxVDB<T>, Scene target
+ *          (src/ray_caster/ray_caster_dpbx_vdb.cu:439-532)
+ * ============================================================================================== */
+
+/* The fields of RayCaster::RenderParameter (include/ray_caster/ray_caster.h:18-28) the marcher reads */
+typedef struct kk_dvr_params {
+    float w2s[16];      /* column-major */
+    float inv_proj[16]; /* column-major */
+    float max_alpha;
+    float sampling_rate;
+    int32_t use_shading;
+    float ka, kd, ks, shiness;
+    float light_pos[3]; /* in volume (voxel) space */
+    float light_col[3];
+} kk_dvr_params;
+
+/* RayCaster::RenderParameterPerFrame (ray_caster.h:29-32) */
+typedef struct kk_dvr_frame {
+    float eye_pos[3];
+    float eye_rot[9];
+} kk_dvr_frame;
+
+/* One frame restricted to pixel rows [y0, y1) (row 0 = bottom row): d_rgba uint8[H][W][4] with alpha =
+ * accumulated opacity. h_vdb is the HOST copy of the device-data struct (its pointers are device
+ * pointers). d_tf float[256][4]. d_counters (optional, uint64[2], zeroed by the caller) accumulates
+ * samples taken and leaf bricks entered. */
+int kk_dvr_render_u8(const kk_vdb_device_data *h_vdb, const float *d_tf, const kk_dvr_params *h_params,
+                     const kk_dvr_frame *h_frame, uint8_t *d_rgba, int width, int height, int y0,
+                     int y1, unsigned long long *d_counters, void *stream);
+int kk_dvr_render_u16(const kk_vdb_device_data *h_vdb, const float *d_tf,
+                      const kk_dvr_params *h_params, const kk_dvr_frame *h_frame, uint8_t *d_rgba,
+                      int width, int height, int y0, int y1, unsigned long long *d_counters,
+                      void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -209,3 +209,88 @@ def rng_uniforms(seed: int, pixel: int, sample: int, count: int) -> np.ndarray:
     lib().ko_rng_uniforms(C.c_uint32(seed), C.c_uint32(pixel), C.c_uint32(sample), C.c_uint32(count),
                           _vp(out))
     return out
+
+
+# ---- Depth-Box VDB and the DVR marcher ----------------------------------------------------------------
+
+VDB_PARAM_DTYPE = np.dtype({
+    "names": ["rootLev", "apronWid", "apronDepWid", "log2Dims", "dims", "voxPerAtlasBrick",
+              "minDepPosValInBrick", "maxDepPosValInBrick", "atlasBrickPerVDB", "nodeStarts",
+              "childStarts", "voxsPerChild", "voxPerVDB", "voxPerVol"],
+    "formats": ["u1", "u1", "u1", ("u1", (3,)), ("<i4", (3,)), "<i4", "<i4", "<i4", ("<i4", (3,)),
+                ("<u8", (3,)), ("<u8", (3,)), ("<f4", (3,)), "<f4", ("<f4", (3,))],
+    "offsets": [0, 1, 2, 3, 8, 20, 24, 28, 32, 48, 72, 96, 108, 112], "itemsize": 128})
+VDB_NODE_DTYPE = np.dtype([("pos", "<i4", (3,)), ("brickPosInAtlas", "<i4", (3,)),
+                           ("childPoolOffsRelative", "<u8")])
+assert VDB_NODE_DTYPE.itemsize == 32
+
+
+class OracleVDB:
+    """Handle of a VDB built by the CPU checker; arrays are copied out on construction."""
+
+    def __init__(self, volume: np.ndarray, log2_dims=(5, 4, 3), apron_wid=1, use_depth_box=True,
+                 empty_ranges=()):
+        vol = np.ascontiguousarray(volume)
+        assert vol.dtype in (np.uint8, np.uint16) and vol.ndim == 3
+        self.is16 = int(vol.dtype == np.uint16)
+        dz, dy, dx = vol.shape
+        rng = np.ascontiguousarray(np.asarray(empty_ranges, vol.dtype).reshape(-1, 2))
+        l2 = np.asarray(log2_dims, np.uint8)
+        fn = lib().ko_vdb_build_u16 if self.is16 else lib().ko_vdb_build_u8
+        fn.restype = C.c_void_p
+        self.handle = fn(_vp(vol), C.c_int(dx), C.c_int(dy), C.c_int(dz), _vp(l2),
+                         C.c_uint8(apron_wid), C.c_int(int(use_depth_box)), _vp(rng),
+                         C.c_uint32(rng.shape[0]))
+        if not self.handle:
+            raise ValueError("the reference would reject this volume / configuration")
+        sizes = np.zeros(5, np.uint64)
+        lib().ko_vdb_sizes(C.c_void_p(self.handle), C.c_int(self.is16), _vp(sizes))
+        self.param = np.zeros((), VDB_PARAM_DTYPE)
+        self.nodes = np.zeros(int(sizes[0]), VDB_NODE_DTYPE)
+        self.child_pools = np.zeros(int(sizes[1]), np.uint32)
+        self.atlas_brick_to_node = np.zeros(int(sizes[2]), np.uint32)
+        self.atlas = np.zeros(int(sizes[3]), vol.dtype)
+        self.leaf_num = int(sizes[4])
+        for what, arr in enumerate((self.param, self.nodes, self.child_pools,
+                                    self.atlas_brick_to_node, self.atlas)):
+            lib().ko_vdb_get(C.c_void_p(self.handle), C.c_int(self.is16), C.c_int(what), _vp(arr))
+        A = int(self.param["voxPerAtlasBrick"])
+        self.atlas = self.atlas.reshape(self.leaf_num, A, A, A)
+
+    def __del__(self):
+        if getattr(self, "handle", None):
+            lib().ko_vdb_free(C.c_void_p(self.handle), C.c_int(self.is16))
+            self.handle = None
+
+
+class _KoDvrParams(C.Structure):
+    _fields_ = [("w2s", C.c_float * 16), ("invProj", C.c_float * 16), ("eyePos", C.c_float * 3),
+                ("eyeRot", C.c_float * 9), ("maxAlpha", C.c_float), ("samplingRate", C.c_float),
+                ("useShading", C.c_int32), ("ka", C.c_float), ("kd", C.c_float), ("ks", C.c_float),
+                ("shiness", C.c_float), ("lightPos", C.c_float * 3), ("lightCol", C.c_float * 3)]
+
+
+def dvr_render(vdb: OracleVDB, tf: np.ndarray, w2s, inv_proj, eye_pos, eye_rot, W: int, H: int,
+               max_alpha=0.9, sampling_rate=3.0, shading=None, rows=None, rgba=None):
+    """One RenderDepthBoxVDB(Scene) frame on the CPU -> (rgba [H,W,4] u8, number of samples taken)."""
+    pr = _KoDvrParams()
+    for name, val in (("w2s", w2s), ("invProj", inv_proj), ("eyePos", eye_pos), ("eyeRot", eye_rot)):
+        arr = getattr(pr, name)
+        for i, x in enumerate(np.asarray(val, np.float32).reshape(-1)):
+            arr[i] = float(x)
+    pr.maxAlpha, pr.samplingRate = max_alpha, sampling_rate
+    pr.useShading = 0
+    if shading is not None:
+        pr.useShading = 1
+        pr.ka, pr.kd, pr.ks, pr.shiness = (shading[k] for k in ("ka", "kd", "ks", "shiness"))
+        for i in range(3):
+            pr.lightPos[i] = float(shading["lightPosInVolumeSpace"][i])
+            pr.lightCol[i] = float(shading["lightCol"][i])
+    tf = np.ascontiguousarray(tf, np.float32).reshape(256, 4)
+    if rgba is None:
+        rgba = np.zeros((H, W, 4), np.uint8)
+    y0, y1 = rows if rows is not None else (0, H)
+    samples = C.c_uint64(0)
+    lib().ko_dvr_render(C.c_void_p(vdb.handle), C.c_int(vdb.is16), _vp(tf), C.byref(pr), _vp(rgba),
+                        C.c_int(W), C.c_int(H), C.c_int(y0), C.c_int(y1), C.byref(samples))
+    return rgba, int(samples.value)

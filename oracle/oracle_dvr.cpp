@@ -1,0 +1,456 @@
+// TEST INFRASTRUCTURE ONLY (see ko_math.h). CPU restatement of the Depth-Box VDB ray marcher:
+// RayCaster::RenderDepthBoxVDB<T> for the Scene target
+// (src/ray_caster/ray_caster_dpbx_vdb.cu:44-282, 465-531) with VDBStack, HDDA3D and DepthDDA2D of
+// include/ray_caster/dda.h.
+//
+// Texture hardware is restated in software, with these stated conventions (CUDA's filtering weights
+// are quantised to 8 fractional bits, which nothing here can reproduce or check: "sub-1/256
+// interpolation-weight parity unpinned"):
+//   atlasTex    linear, non-normalised coordinates, normalised-float read (include/cuda/texture.h:93-98):
+//               xB = x - 0.5, i = floor(xB), a = xB - i with full fp32 weights, float(value) / max(T),
+//               combined as ((1-a) v0 + a v1) along x, then y, then z;
+//   atlasDepTex point, element type (src/ray_caster/dpbx_vdb.cu:158-167): voxel at floor(coordinate);
+//   tfTex       1-D float4, normalised coordinates, linear, border 0 (app/dvr_dpbx_vdb.cpp:257-266):
+//               x = u * 256 - 0.5, i = floor(x), a = x - i, (1-a) tf[i] + a tf[i+1], 0 outside [0,255].
+#include "ko_vdb.h"
+
+#include <cstring>
+
+using namespace ko;
+
+namespace {
+
+constexpr float Eps = .01f; // include/ray_caster/dda.h:11
+
+struct RenderParam {
+    mat4 w2s, invProj;
+    vec3 eyePos;
+    mat3 eyeRot;
+    float maxAlpha, samplingRate;
+    bool useShading;
+    float ka, kd, ks, shiness;
+    vec3 lightPos, lightCol;
+};
+
+inline int sgn(float d) { return d > 0.f ? 1 : d < 0.f ? -1 : 0; }
+
+// include/ray_caster/dda.h:35-82
+struct HDDA3D {
+    int sign[3], mask[3], chPos[3];
+    float tCurr, tNext;
+    vec3 tSide, tDlt;
+    vec3 pos, dir;
+
+    static HDDA3D Create(float tCurr, const Ray &ray) {
+        HDDA3D h;
+        h.pos = ray.pos;
+        h.dir = ray.dir;
+        for (int k = 0; k < 3; ++k) {
+            h.sign[k] = sgn(ray.dir[k]);
+            h.mask[k] = 0;
+            h.chPos[k] = 0;
+        }
+        h.tCurr = tCurr;
+        h.tNext = 0.f;
+        return h;
+    }
+    void Prepare(vec3 min, float voxPerChild) {
+        tDlt = vabs(voxPerChild / dir);
+        vec3 pFlt = (pos + tCurr * dir - min) / voxPerChild;
+        vec3 s = {static_cast<float>(sign[0]), static_cast<float>(sign[1]), static_cast<float>(sign[2])};
+        tSide = ((vfloor(pFlt) - pFlt + .5f) * s + .5f) * tDlt + tCurr;
+        vec3 f = vfloor(pFlt);
+        chPos[0] = static_cast<int>(f.x);
+        chPos[1] = static_cast<int>(f.y);
+        chPos[2] = static_cast<int>(f.z);
+    }
+    void Next() {
+        mask[0] = static_cast<int>((tSide.x < tSide.y) & (tSide.x <= tSide.z));
+        mask[1] = static_cast<int>((tSide.y < tSide.z) & (tSide.y <= tSide.x));
+        mask[2] = static_cast<int>((tSide.z < tSide.x) & (tSide.z <= tSide.y));
+        tNext = mask[0] ? tSide.x : mask[1] ? tSide.y : mask[2] ? tSide.z : INFINITY;
+    }
+    void Step() {
+        tCurr = tNext;
+        tSide.x = std::isinf(tDlt.x) ? INFINITY : mask[0] ? tSide.x + tDlt.x : tSide.x;
+        tSide.y = std::isinf(tDlt.y) ? INFINITY : mask[1] ? tSide.y + tDlt.y : tSide.y;
+        tSide.z = std::isinf(tDlt.z) ? INFINITY : mask[2] ? tSide.z + tDlt.z : tSide.z;
+        for (int k = 0; k < 3; ++k)
+            chPos[k] += mask[k] * sign[k];
+    }
+};
+
+// include/ray_caster/dda.h:84-172
+struct DepthDDA2D {
+    int sign[3], mask[3], posInBrick[3];
+    float t, tStart, dep, tDlt2Dep;
+    vec3 tSide, tDlt;
+
+    bool Init(float t_, float maxPosValInBrick, int minDepPosValInBrick, int maxDepPosValInBrick,
+              vec3 pib, const Ray &ray) {
+        dep = 0.f;
+        tDlt2Dep = 0.f;
+        for (int k = 0; k < 3; ++k) {
+            sign[k] = sgn(ray.dir[k]);
+            mask[k] = 0;
+        }
+        t = tStart = t_;
+        int depSign[3];
+        {
+            vec3 d;
+            for (int k = 0; k < 3; ++k)
+                d[k] = sign[k] == 0 ? INFINITY : sign[k] > 0 ? pib[k] : maxPosValInBrick - pib[k];
+            depSign[0] = d.x < d.y && d.x <= d.z ? sign[0] : 0;
+            depSign[1] = d.y < d.z && d.y <= d.x ? sign[1] : 0;
+            depSign[2] = d.z < d.x && d.z <= d.y ? sign[2] : 0;
+            if (depSign[0] != 0 && d.x >= .5f)
+                return false;
+            if (depSign[1] != 0 && d.y >= .5f)
+                return false;
+            if (depSign[2] != 0 && d.z >= .5f)
+                return false;
+        }
+        tDlt = vabs(1.f / ray.dir);
+        vec3 f = vfloor(pib);
+        posInBrick[0] = static_cast<int>(f.x);
+        posInBrick[1] = static_cast<int>(f.y);
+        posInBrick[2] = static_cast<int>(f.z);
+        vec3 s = {static_cast<float>(sign[0]), static_cast<float>(sign[1]), static_cast<float>(sign[2])};
+        tSide = ((vfloor(pib) - pib + .5f) * s + .5f) * tDlt + t;
+        for (int k = 0; k < 3; ++k)
+            if (depSign[k] != 0) {
+                posInBrick[k] = depSign[k] == 1 ? minDepPosValInBrick : maxDepPosValInBrick;
+                sign[k] = 0;
+                tSide[k] = INFINITY;
+                tDlt2Dep = std::fabs(ray.dir[k]);
+            }
+        return (depSign[0] | depSign[1] | depSign[2]) != 0;
+    }
+    void StepNext() {
+        mask[0] = static_cast<int>((tSide.x < tSide.y) & (tSide.x <= tSide.z));
+        mask[1] = static_cast<int>((tSide.y < tSide.z) & (tSide.y <= tSide.x));
+        mask[2] = static_cast<int>((tSide.z < tSide.x) & (tSide.z <= tSide.y));
+        t = mask[0] ? tSide.x : mask[1] ? tSide.y : mask[2] ? tSide.z : INFINITY;
+        dep = tDlt2Dep * (t - tStart);
+        tSide.x = std::isinf(tDlt.x) ? INFINITY : mask[0] ? tSide.x + tDlt.x : tSide.x;
+        tSide.y = std::isinf(tDlt.y) ? INFINITY : mask[1] ? tSide.y + tDlt.y : tSide.y;
+        tSide.z = std::isinf(tDlt.z) ? INFINITY : mask[2] ? tSide.z + tDlt.z : tSide.z;
+        for (int k = 0; k < 3; ++k)
+            posInBrick[k] += mask[k] * sign[k];
+    }
+};
+
+template <typename T> struct Marcher {
+    const VDB<T> &vdb;
+    const float *tf; // 256 x rgba
+    const RenderParam &rp;
+    uint64_t samples = 0;
+
+    // voxel of the atlas at global atlas coordinate (gx, gy, gz); 0 outside (border)
+    T atlasAt(int gx, int gy, int gz) const {
+        const VDBParameter &p = vdb.param;
+        const int A = p.voxPerAtlasBrick;
+        if (gx < 0 || gy < 0 || gz < 0 || gx >= A * p.atlasBrickPerVDB[0] ||
+            gy >= A * p.atlasBrickPerVDB[1] || gz >= A * p.atlasBrickPerVDB[2])
+            return 0;
+        int bx = gx / A, by = gy / A, bz = gz / A;
+        uint32_t k = vdb.atlasBrickToNodeIndices[(static_cast<size_t>(bz) * p.atlasBrickPerVDB[1] + by) *
+                                                     p.atlasBrickPerVDB[0] + bx];
+        if (k == UndefRltIdx)
+            return 0; // atlas brick that holds no leaf: never sampled by a ray inside a valid brick
+        size_t off = static_cast<size_t>(k) * A * A * A +
+                     (static_cast<size_t>(gz - bz * A) * A + (gy - by * A)) * A + (gx - bx * A);
+        return vdb.atlas[off];
+    }
+    float atlasLinear(vec3 sp) const {
+        constexpr float maxT = static_cast<float>(std::numeric_limits<T>::max());
+        vec3 b = sp - .5f;
+        vec3 f = vfloor(b);
+        int i = static_cast<int>(f.x), j = static_cast<int>(f.y), k = static_cast<int>(f.z);
+        float ax = b.x - f.x, ay = b.y - f.y, az = b.z - f.z;
+        float v[2][2][2];
+        for (int dz = 0; dz < 2; ++dz)
+            for (int dy = 0; dy < 2; ++dy)
+                for (int dx = 0; dx < 2; ++dx)
+                    v[dz][dy][dx] = static_cast<float>(atlasAt(i + dx, j + dy, k + dz)) / maxT;
+        float c00 = (1.f - ax) * v[0][0][0] + ax * v[0][0][1];
+        float c01 = (1.f - ax) * v[0][1][0] + ax * v[0][1][1];
+        float c10 = (1.f - ax) * v[1][0][0] + ax * v[1][0][1];
+        float c11 = (1.f - ax) * v[1][1][0] + ax * v[1][1][1];
+        float c0 = (1.f - ay) * c00 + ay * c01;
+        float c1 = (1.f - ay) * c10 + ay * c11;
+        return (1.f - az) * c0 + az * c1;
+    }
+    T atlasPoint(float x, float y, float z) const {
+        return atlasAt(static_cast<int>(std::floor(x)), static_cast<int>(std::floor(y)),
+                       static_cast<int>(std::floor(z)));
+    }
+    vec4 tfLinear(float u) const {
+        float x = u * 256.f - .5f;
+        float fl = std::floor(x);
+        int i = static_cast<int>(fl);
+        float a = x - fl;
+        vec4 t0 = {0, 0, 0, 0}, t1 = {0, 0, 0, 0};
+        if (i >= 0 && i <= 255)
+            t0 = {tf[4 * i], tf[4 * i + 1], tf[4 * i + 2], tf[4 * i + 3]};
+        if (i + 1 >= 0 && i + 1 <= 255)
+            t1 = {tf[4 * i + 4], tf[4 * i + 5], tf[4 * i + 6], tf[4 * i + 7]};
+        return (1.f - a) * t0 + a * t1;
+    }
+
+    struct InLeaf {
+        float tCurr, tExit;
+        Node leaf;
+    };
+
+    // ray_caster_dpbx_vdb.cu:139-162
+    bool depthSkip(InLeaf &param, vec3 posInBrick, vec3 atlasBrickMinVoxPos, const Ray &eyeRay) const {
+        const VDBParameter &p = vdb.param;
+        DepthDDA2D d;
+        if (!d.Init(param.tCurr, p.voxsPerChild[1], p.minDepPosValInBrick, p.maxDepPosValInBrick,
+                    posInBrick, eyeRay))
+            return false;
+        while (true) {
+            T dep = atlasPoint(atlasBrickMinVoxPos.x + d.posInBrick[0],
+                               atlasBrickMinVoxPos.y + d.posInBrick[1],
+                               atlasBrickMinVoxPos.z + d.posInBrick[2]);
+            if (dep <= d.dep)
+                break;
+            if (d.t >= param.tExit)
+                return true;
+            param.tCurr = d.t;
+            d.StepNext();
+        }
+        return false;
+    }
+
+    // ray_caster_dpbx_vdb.cu:164-282 around rayCastVDB :44-137
+    void renderScene(Ray eyeRay, uint8_t out[4]) {
+        const VDBParameter &p = vdb.param;
+        const bool useDepthBox = p.apronDepWid != p.apronWid;
+        vec3 rgb = {0.f, 0.f, 0.f};
+        float a = 0.f;
+        float step = 0.f;
+        uint32_t maxStepCnt = 0;
+        vec3 dltPos = {0.f, 0.f, 0.f};
+        const vec3 voxPerVol = {p.voxPerVol[0], p.voxPerVol[1], p.voxPerVol[2]};
+
+        auto finish = [&]() {
+            rgb = rgb / (rgb + 1.f);
+            for (int k = 0; k < 3; ++k)
+                rgb[k] = std::pow(rgb[k], 1.f / 2.2f);
+            out[0] = static_cast<uint8_t>(255.f * rgb.x);
+            out[1] = static_cast<uint8_t>(255.f * rgb.y);
+            out[2] = static_cast<uint8_t>(255.f * rgb.z);
+            out[3] = static_cast<uint8_t>(255.f * a);
+        };
+
+        auto inLeaf = [&](InLeaf &param) -> bool {
+            param.tCurr = step * std::ceil(param.tCurr / step);
+            vec3 brickMinVoxPos = {static_cast<float>(param.leaf.pos[0]),
+                                   static_cast<float>(param.leaf.pos[1]),
+                                   static_cast<float>(param.leaf.pos[2])};
+            vec3 posInBrick = eyeRay.pos + param.tCurr * eyeRay.dir - brickMinVoxPos;
+            vec3 atlasBrickMinVoxPos = {
+                static_cast<float>(param.leaf.brickPosInAtlas[0] * p.voxPerAtlasBrick + p.apronDepWid),
+                static_cast<float>(param.leaf.brickPosInAtlas[1] * p.voxPerAtlasBrick + p.apronDepWid),
+                static_cast<float>(param.leaf.brickPosInAtlas[2] * p.voxPerAtlasBrick + p.apronDepWid)};
+            if (useDepthBox) {
+                if (depthSkip(param, posInBrick, atlasBrickMinVoxPos, eyeRay))
+                    return true;
+                param.tCurr = step * std::ceil(param.tCurr / step);
+                posInBrick = eyeRay.pos + param.tCurr * eyeRay.dir - brickMinVoxPos;
+            }
+            while (param.tCurr < param.tExit && [&]() {
+                for (int k = 0; k < 3; ++k)
+                    if (posInBrick[k] < 0.f || posInBrick[k] >= p.voxsPerChild[1])
+                        return false;
+                return true;
+            }()) {
+                vec3 samplePos = atlasBrickMinVoxPos + posInBrick;
+                float scalar = atlasLinear(samplePos);
+                vec4 tfCol = tfLinear(scalar);
+                vec3 tfColRGB = {tfCol.x, tfCol.y, tfCol.z};
+                ++samples;
+                if (rp.useShading) {
+                    vec3 N;
+                    for (int k = 0; k < 3; ++k) {
+                        samplePos[k] += .5f;
+                        float v0 = atlasLinear(samplePos);
+                        samplePos[k] -= 1.f;
+                        float v1 = atlasLinear(samplePos);
+                        N[k] = v1 - v0;
+                    }
+                    N = normalize(N);
+                    if (dot(eyeRay.dir, N) > 0.f)
+                        N = -N;
+                    vec3 p2lDir = normalize(rp.lightPos - brickMinVoxPos - posInBrick);
+                    vec3 ambient = rp.ka * tfColRGB;
+                    vec3 diffuse = rp.kd * gmax(0.f, dot(N, p2lDir)) * tfColRGB * rp.lightCol;
+                    vec3 hfDir = normalize(p2lDir - eyeRay.dir);
+                    vec3 specular = rp.ks * std::pow(gmax(0.f, dot(N, hfDir)), rp.shiness) * rp.lightCol;
+                    for (int k = 0; k < 3; ++k)
+                        tfColRGB[k] = ambient[k] + diffuse[k] + specular[k];
+                }
+                rgb = rgb + (1.f - a) * tfCol.w * tfColRGB;
+                a = a + (1.f - a) * tfCol.w;
+                if (a >= rp.maxAlpha)
+                    return false;
+                param.tCurr += step;
+                posInBrick += dltPos;
+            }
+            return true;
+        };
+
+        // ---- rayCastVDB ----
+        AABB unit{{0.f, 0.f, 0.f}, {1.f, 1.f, 1.f}};
+        HitShell hit = HitAABB(eyeRay, unit);
+        if (hit.tEnter >= hit.tExit)
+            return finish();
+        {
+            float tDlt = hit.tExit - hit.tEnter;
+            vec3 d = tDlt * eyeRay.dir;
+            maxStepCnt = static_cast<uint32_t>(
+                std::ceil(rp.samplingRate * length(d) * gmax(voxPerVol.x, gmax(voxPerVol.y, voxPerVol.z))));
+        }
+        eyeRay.pos *= voxPerVol;
+        eyeRay.dir = normalize(eyeRay.dir * voxPerVol);
+        hit = HitAABB(eyeRay, AABB{{0.f, 0.f, 0.f}, voxPerVol});
+        if (hit.tEnter >= hit.tExit)
+            return finish();
+        {
+            float tDlt = hit.tExit - hit.tEnter;
+            step = tDlt / (maxStepCnt - 1);
+            dltPos = step * eyeRay.dir;
+        }
+        hit = HitAABB(eyeRay, AABB{{0.f, 0.f, 0.f}, {p.voxPerVDB, p.voxPerVDB, p.voxPerVDB}});
+        if (hit.tEnter >= hit.tExit)
+            return finish();
+
+        // VDBStack (dda.h:13-33)
+        int lev = p.rootLev + 1;
+        float tExits[MaxLevelNum - 1] = {0.f, 0.f};
+        Node nodes[MaxLevelNum - 1] = {};
+        auto push = [&](uint32_t rel, float tExit) {
+            --lev;
+            nodes[lev - 1] = vdb.GetNode(static_cast<uint8_t>(lev), rel);
+            tExits[lev - 1] = tExit;
+        };
+        auto empty = [&]() { return lev == p.rootLev + 1; };
+        auto nodePos = [&]() {
+            return vec3{static_cast<float>(nodes[lev - 1].pos[0]), static_cast<float>(nodes[lev - 1].pos[1]),
+                        static_cast<float>(nodes[lev - 1].pos[2])};
+        };
+
+        push(0, hit.tExit - Eps);
+        HDDA3D h = HDDA3D::Create(hit.tEnter + Eps, eyeRay);
+        h.Prepare({0.f, 0.f, 0.f}, p.voxsPerChild[p.rootLev]);
+
+        while (!empty() && [&]() {
+            for (int k = 0; k < 3; ++k)
+                if (h.chPos[k] < 0 || h.chPos[k] >= p.dims[lev])
+                    return false;
+            return true;
+        }()) {
+            h.Next();
+            const Node &curr = nodes[lev - 1];
+            uint32_t ch = vdb.GetChild(static_cast<uint8_t>(lev), curr.childPoolOffsRelative, h.chPos);
+            if (ch != UndefRltIdx) {
+                if (lev == 1) {
+                    h.tCurr += Eps;
+                    InLeaf param{h.tCurr, h.tNext - Eps, vdb.GetNode(0, ch)};
+                    if (!inLeaf(param))
+                        break;
+                    h.Step();
+                } else {
+                    push(ch, h.tNext - Eps);
+                    h.tCurr += Eps;
+                    h.Prepare(nodePos(), p.voxsPerChild[lev]);
+                }
+            } else
+                h.Step();
+
+            while (h.tCurr >= tExits[lev - 1]) {
+                ++lev;
+                if (empty())
+                    break;
+                h.Prepare(nodePos(), p.voxsPerChild[lev]);
+            }
+        }
+        finish();
+    }
+};
+
+template <typename T>
+void renderDVR(const VDB<T> &vdb, const float *tf, const RenderParam &rp, uint8_t *rgba, int W, int H,
+               int y0, int y1, uint64_t *samplesOut) {
+    uint64_t total = 0;
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : total)
+    for (int y = y0; y < y1; ++y) {
+        Marcher<T> m{vdb, tf, rp};
+        for (int x = 0; x < W; ++x) {
+            // ray_caster_dpbx_vdb.cu:475-501
+            Ray eyeRay;
+            vec4 tmp;
+            tmp.z = static_cast<float>(W);
+            tmp.w = static_cast<float>(H);
+            tmp.x = (2.f * x + 1.f - tmp.z) / tmp.z;
+            tmp.y = (2.f * y + 1.f - tmp.w) / tmp.w;
+            tmp.z = 1.f;
+            tmp.w = 1.f;
+            tmp = rp.invProj * tmp;
+            eyeRay.dir = {tmp.x, tmp.y, tmp.z};
+            eyeRay.dir = rp.eyeRot * normalize(eyeRay.dir);
+            tmp = {eyeRay.dir.x, eyeRay.dir.y, eyeRay.dir.z, 0.f};
+            tmp = rp.w2s * tmp;
+            eyeRay.dir = {tmp.x, tmp.y, tmp.z};
+            eyeRay.dir = normalize(eyeRay.dir);
+            tmp = {rp.eyePos.x, rp.eyePos.y, rp.eyePos.z, 1.f};
+            tmp = rp.w2s * tmp;
+            eyeRay.pos = {tmp.x, tmp.y, tmp.z};
+            m.renderScene(eyeRay, rgba + 4 * (static_cast<size_t>(y) * W + x));
+        }
+        total += m.samples;
+    }
+    if (samplesOut)
+        *samplesOut = total;
+}
+
+} // namespace
+
+extern "C" {
+
+struct ko_dvr_params {
+    float w2s[16], invProj[16];
+    float eyePos[3], eyeRot[9];
+    float maxAlpha, samplingRate;
+    int32_t useShading;
+    float ka, kd, ks, shiness;
+    float lightPos[3], lightCol[3];
+};
+
+void ko_dvr_render(const void *vdbHandle, int is16, const float *tf256x4, const ko_dvr_params *pr,
+                   uint8_t *rgba, int W, int H, int y0, int y1, uint64_t *samplesOut) {
+    RenderParam rp;
+    std::memcpy(&rp.w2s, pr->w2s, 64);
+    std::memcpy(&rp.invProj, pr->invProj, 64);
+    rp.eyePos = {pr->eyePos[0], pr->eyePos[1], pr->eyePos[2]};
+    std::memcpy(&rp.eyeRot, pr->eyeRot, 36);
+    rp.maxAlpha = pr->maxAlpha;
+    rp.samplingRate = pr->samplingRate;
+    rp.useShading = pr->useShading != 0;
+    rp.ka = pr->ka;
+    rp.kd = pr->kd;
+    rp.ks = pr->ks;
+    rp.shiness = pr->shiness;
+    rp.lightPos = {pr->lightPos[0], pr->lightPos[1], pr->lightPos[2]};
+    rp.lightCol = {pr->lightCol[0], pr->lightCol[1], pr->lightCol[2]};
+    if (is16)
+        renderDVR(*static_cast<const VDB<uint16_t> *>(vdbHandle), tf256x4, rp, rgba, W, H, y0, y1,
+                  samplesOut);
+    else
+        renderDVR(*static_cast<const VDB<uint8_t> *>(vdbHandle), tf256x4, rp, rgba, W, H, y0, y1,
+                  samplesOut);
+}
+
+} // extern "C"

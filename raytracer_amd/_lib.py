@@ -29,6 +29,41 @@ class LbvhDeviceData(C.Structure):
 
 assert C.sizeof(LbvhDeviceData) == 64
 
+
+class VdbParam(C.Structure):
+    _fields_ = [("root_lev", C.c_uint8), ("apron_wid", C.c_uint8), ("apron_dep_wid", C.c_uint8),
+                ("log2_dims", C.c_uint8 * 3), ("dims", C.c_int32 * 3), ("vox_per_atlas_brick", C.c_int32),
+                ("min_dep_pos_val_in_brick", C.c_int32), ("max_dep_pos_val_in_brick", C.c_int32),
+                ("atlas_brick_per_vdb", C.c_int32 * 3), ("node_starts", C.c_uint64 * 3),
+                ("child_starts", C.c_uint64 * 3), ("voxs_per_child", C.c_float * 3),
+                ("vox_per_vdb", C.c_float), ("vox_per_vol", C.c_float * 3), ("_pad", C.c_uint32)]
+
+
+class VdbDeviceData(C.Structure):
+    _fields_ = [("node_pools", C.c_void_p), ("child_pools", C.c_void_p),
+                ("atlas_brick_to_node_indices", C.c_void_p), ("atlas", C.c_void_p),
+                ("leaf_num", C.c_uint64), ("voxel_bytes", C.c_uint64), ("vdb_param", VdbParam)]
+
+
+class VdbPlan(C.Structure):
+    _fields_ = [("param", VdbParam), ("leaf_slots", C.c_uint32 * 3), ("leaf_num", C.c_uint32),
+                ("node_num", C.c_uint64), ("child_num", C.c_uint64), ("atlas_map_num", C.c_uint64),
+                ("atlas_voxels", C.c_uint64)]
+
+
+class DvrParams(C.Structure):
+    _fields_ = [("w2s", C.c_float * 16), ("inv_proj", C.c_float * 16), ("max_alpha", C.c_float),
+                ("sampling_rate", C.c_float), ("use_shading", C.c_int32), ("ka", C.c_float),
+                ("kd", C.c_float), ("ks", C.c_float), ("shiness", C.c_float),
+                ("light_pos", C.c_float * 3), ("light_col", C.c_float * 3)]
+
+
+class DvrFrame(C.Structure):
+    _fields_ = [("eye_pos", C.c_float * 3), ("eye_rot", C.c_float * 9)]
+
+
+assert C.sizeof(VdbParam) == 128 and C.sizeof(VdbDeviceData) == 176 and C.sizeof(VdbPlan) == 176
+
 KK_LBVH_KEEP_STAGES = 1
 KK_TRAVERSE_ORDERED = 0
 
@@ -55,6 +90,12 @@ def _declare(l):
     l.kk_closest_hit.argtypes = [vp, vp, vp, vp, u32, vp, vp, vp, i32, vp, vp, sz, vp]
     l.kk_pt_render_sample.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, C.c_float, u32, vp]
     l.kk_rng_uniforms.argtypes = [u32, u32, u32, u32, vp, vp]
+    for sfx in ("u8", "u16"):
+        getattr(l, f"kk_vdb_classify_{sfx}").argtypes = [vp, u32, u32, u32, u32, vp, u32, vp, vp]
+        getattr(l, f"kk_vdb_fill_atlas_{sfx}").argtypes = [vp, u32, u32, u32, vp, vp, vp, u32, vp, vp]
+        getattr(l, f"kk_dvr_render_{sfx}").argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]
+    l.kk_vdb_plan_build.argtypes = [u32, u32, u32, vp, C.c_uint8, i32, vp, vp]
+    l.kk_vdb_wire.argtypes = [vp, vp, vp, vp, vp]
     for name in ("kk_malloc", "kk_free", "kk_memcpy_h2d", "kk_memcpy_d2h", "kk_memset",
                  "kk_stream_synchronize", "kk_set_device"):
         getattr(l, name).restype = i32

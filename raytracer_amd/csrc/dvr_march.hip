@@ -1,0 +1,491 @@
+// Direct volume rendering of a Depth-Box VDB: RayCaster::RenderDepthBoxVDB<T>, Scene target
+// (src/ray_caster/ray_caster_dpbx_vdb.cu:44-282, 465-531; VDBStack / HDDA3D / DepthDDA2D of
+// include/ray_caster/dda.h), one lane per pixel, a wave covers an 8 x 8 pixel tile so that its lanes
+// walk the same bricks.
+//
+// What replaces the CUDA texture units:
+//   * the atlas is stored brick by brick (voxPerAtlasBrick^3 voxels, x fastest, brick k = leaf node k),
+//     so the eight voxels of a trilinear sample come from one contiguous 46 KB block; the sample
+//     coordinate is still formed in the reference's global atlas coordinates (brickPosInAtlas * 36 + 2
+//     + posInBrick, in fp32) and only then reduced to the brick, so it rounds like the reference's;
+//   * trilinear filtering in fp32: xB = x - 0.5, i = floor(xB), a = xB - i, value = float(v) / max(T),
+//     ((1-a) v0 + a v1) along x, then y, then z (CUDA quantises a to 8 fractional bits; not reproduced);
+//   * depth-shell reads are point reads of the element type;
+//   * the 256-entry transfer function sits in LDS; lookup x = u * 256 - 0.5, linear, 0 outside.
+#include "kk_host.h"
+#include "kk_math.h"
+
+namespace kk {
+namespace dvr {
+
+constexpr int THREADS = 256;
+constexpr float Eps = .01f; // include/ray_caster/dda.h:11
+constexpr uint32_t UndefRltIdx = 0xFFFFFFFFu;
+
+KK_D int sgn(float d) { return d > 0.f ? 1 : d < 0.f ? -1 : 0; }
+KK_D f3 toF3(const int p[3]) {
+    return {static_cast<float>(p[0]), static_cast<float>(p[1]), static_cast<float>(p[2])};
+}
+KK_D f3 toF3(i3 p) { return {static_cast<float>(p.x), static_cast<float>(p.y), static_cast<float>(p.z)}; }
+KK_D bool isInf(float x) { return fabsf(x) == INFINITY; }
+
+// include/ray_caster/dda.h:35-82
+struct HDDA3D {
+    i3 sign, mask, chPos;
+    float tCurr, tNext;
+    f3 tSide, tDlt;
+
+    KK_D void Prepare(const Ray &ray, f3 min, float voxPerChild) {
+        tDlt = vabs(voxPerChild / ray.dir);
+        const f3 pFlt = (ray.pos + tCurr * ray.dir - min) / voxPerChild;
+        const f3 fl = vfloor(pFlt);
+        tSide = ((fl - pFlt + .5f) * toF3(sign) + .5f) * tDlt + tCurr;
+        chPos = {static_cast<int>(fl.x), static_cast<int>(fl.y), static_cast<int>(fl.z)};
+    }
+    KK_D void Next() {
+        mask.x = static_cast<int>((tSide.x < tSide.y) & (tSide.x <= tSide.z));
+        mask.y = static_cast<int>((tSide.y < tSide.z) & (tSide.y <= tSide.x));
+        mask.z = static_cast<int>((tSide.z < tSide.x) & (tSide.z <= tSide.y));
+        tNext = mask.x ? tSide.x : mask.y ? tSide.y : mask.z ? tSide.z : INFINITY;
+    }
+    KK_D void Step() {
+        tCurr = tNext;
+        tSide.x = isInf(tDlt.x) ? INFINITY : mask.x ? tSide.x + tDlt.x : tSide.x;
+        tSide.y = isInf(tDlt.y) ? INFINITY : mask.y ? tSide.y + tDlt.y : tSide.y;
+        tSide.z = isInf(tDlt.z) ? INFINITY : mask.z ? tSide.z + tDlt.z : tSide.z;
+        chPos.x += mask.x * sign.x;
+        chPos.y += mask.y * sign.y;
+        chPos.z += mask.z * sign.z;
+    }
+};
+
+// include/ray_caster/dda.h:84-172
+struct DepthDDA2D {
+    i3 sign, mask, posInBrick;
+    float t, tStart, dep, tDlt2Dep;
+    f3 tSide, tDlt;
+
+    KK_D bool Init(float t_, float maxPosValInBrick, int minDepPos, int maxDepPos, f3 pib,
+                   const Ray &ray) {
+        dep = 0.f;
+        tDlt2Dep = 0.f;
+        sign = {sgn(ray.dir.x), sgn(ray.dir.y), sgn(ray.dir.z)};
+        mask = {0, 0, 0};
+        t = tStart = t_;
+        i3 depSign;
+        {
+            const f3 d = {sign.x == 0 ? INFINITY : sign.x > 0 ? pib.x : maxPosValInBrick - pib.x,
+                          sign.y == 0 ? INFINITY : sign.y > 0 ? pib.y : maxPosValInBrick - pib.y,
+                          sign.z == 0 ? INFINITY : sign.z > 0 ? pib.z : maxPosValInBrick - pib.z};
+            depSign.x = d.x < d.y && d.x <= d.z ? sign.x : 0;
+            depSign.y = d.y < d.z && d.y <= d.x ? sign.y : 0;
+            depSign.z = d.z < d.x && d.z <= d.y ? sign.z : 0;
+            if (depSign.x != 0 && d.x >= .5f)
+                return false;
+            if (depSign.y != 0 && d.y >= .5f)
+                return false;
+            if (depSign.z != 0 && d.z >= .5f)
+                return false;
+        }
+        tDlt = vabs(1.f / ray.dir);
+        const f3 fl = vfloor(pib);
+        posInBrick = {static_cast<int>(fl.x), static_cast<int>(fl.y), static_cast<int>(fl.z)};
+        tSide = ((fl - pib + .5f) * toF3(sign) + .5f) * tDlt + t;
+        if (depSign.x != 0) {
+            posInBrick.x = depSign.x == 1 ? minDepPos : maxDepPos;
+            sign.x = 0;
+            tSide.x = INFINITY;
+            tDlt2Dep = fabsf(ray.dir.x);
+        }
+        if (depSign.y != 0) {
+            posInBrick.y = depSign.y == 1 ? minDepPos : maxDepPos;
+            sign.y = 0;
+            tSide.y = INFINITY;
+            tDlt2Dep = fabsf(ray.dir.y);
+        }
+        if (depSign.z != 0) {
+            posInBrick.z = depSign.z == 1 ? minDepPos : maxDepPos;
+            sign.z = 0;
+            tSide.z = INFINITY;
+            tDlt2Dep = fabsf(ray.dir.z);
+        }
+        return (depSign.x | depSign.y | depSign.z) != 0;
+    }
+    KK_D void StepNext() {
+        mask.x = static_cast<int>((tSide.x < tSide.y) & (tSide.x <= tSide.z));
+        mask.y = static_cast<int>((tSide.y < tSide.z) & (tSide.y <= tSide.x));
+        mask.z = static_cast<int>((tSide.z < tSide.x) & (tSide.z <= tSide.y));
+        t = mask.x ? tSide.x : mask.y ? tSide.y : mask.z ? tSide.z : INFINITY;
+        dep = tDlt2Dep * (t - tStart);
+        tSide.x = isInf(tDlt.x) ? INFINITY : mask.x ? tSide.x + tDlt.x : tSide.x;
+        tSide.y = isInf(tDlt.y) ? INFINITY : mask.y ? tSide.y + tDlt.y : tSide.y;
+        tSide.z = isInf(tDlt.z) ? INFINITY : mask.z ? tSide.z + tDlt.z : tSide.z;
+        posInBrick.x += mask.x * sign.x;
+        posInBrick.y += mask.y * sign.y;
+        posInBrick.z += mask.z * sign.z;
+    }
+};
+
+template <typename T> struct MaxOf;
+template <> struct MaxOf<uint8_t> {
+    static constexpr float value = 255.f;
+};
+template <> struct MaxOf<uint16_t> {
+    static constexpr float value = 65535.f;
+};
+
+// Trilinear sample of one brick. `sp` is the sample position in global atlas voxel coordinates,
+// `origin` the brick's first voxel in those coordinates.
+template <typename T>
+KK_D float sampleBrick(const T *__restrict__ brick, int A, i3 origin, f3 sp) {
+    const f3 b = sp - .5f;
+    const f3 fl = vfloor(b);
+    const float ax = b.x - fl.x, ay = b.y - fl.y, az = b.z - fl.z;
+    int i = static_cast<int>(fl.x) - origin.x;
+    int j = static_cast<int>(fl.y) - origin.y;
+    int k = static_cast<int>(fl.z) - origin.z;
+    // A ray inside a brick's [0, dims0) box with the apron around it never leaves [0, A-2]; the clamp
+    // only guards the address against non-finite coordinates.
+    i = i < 0 ? 0 : (i > A - 2 ? A - 2 : i);
+    j = j < 0 ? 0 : (j > A - 2 ? A - 2 : j);
+    k = k < 0 ? 0 : (k > A - 2 ? A - 2 : k);
+    const T *p = brick + (static_cast<size_t>(k) * A + j) * A + i;
+    const int sy = A, sz = A * A;
+    constexpr float m = MaxOf<T>::value;
+    const float v000 = static_cast<float>(p[0]) / m, v001 = static_cast<float>(p[1]) / m;
+    const float v010 = static_cast<float>(p[sy]) / m, v011 = static_cast<float>(p[sy + 1]) / m;
+    const float v100 = static_cast<float>(p[sz]) / m, v101 = static_cast<float>(p[sz + 1]) / m;
+    const float v110 = static_cast<float>(p[sz + sy]) / m, v111 = static_cast<float>(p[sz + sy + 1]) / m;
+    const float c00 = (1.f - ax) * v000 + ax * v001;
+    const float c01 = (1.f - ax) * v010 + ax * v011;
+    const float c10 = (1.f - ax) * v100 + ax * v101;
+    const float c11 = (1.f - ax) * v110 + ax * v111;
+    const float c0 = (1.f - ay) * c00 + ay * c01;
+    const float c1 = (1.f - ay) * c10 + ay * c11;
+    return (1.f - az) * c0 + az * c1;
+}
+
+KK_D f4 tfLookup(const f4 *__restrict__ s_tf, float u) {
+    const float x = u * 256.f - .5f;
+    const float fl = floorf(x);
+    const float a = x - fl;
+    const int i = static_cast<int>(fl);
+    const f4 zero = {0.f, 0.f, 0.f, 0.f};
+    const f4 t0 = (i >= 0 && i <= 255) ? s_tf[i] : zero;
+    const f4 t1 = (i + 1 >= 0 && i + 1 <= 255) ? s_tf[i + 1] : zero;
+    return t0 * (1.f - a) + t1 * a;
+}
+
+struct InLeaf {
+    float tCurr, tExit;
+};
+
+template <typename T, bool COUNT>
+__global__ __launch_bounds__(THREADS) void dvr_kernel(const kk_vdb_device_data vdb,
+                                                      const float *__restrict__ tf,
+                                                      const kk_dvr_params rp, const kk_dvr_frame fr,
+                                                      uint8_t *__restrict__ rgba, int W, int H, int y0,
+                                                      int y1, unsigned long long *counters) {
+    __shared__ f4 s_tf[256];
+    const int tid = threadIdx.x;
+    s_tf[tid] = reinterpret_cast<const f4 *>(tf)[tid];
+    __syncthreads();
+
+    // 16 x 16 pixel block = 2 x 2 waves of 8 x 8 pixels
+    const int lane = tid & 63, wave = tid >> 6;
+    const int x = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
+    const int y = y0 + blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
+    unsigned long long nSamples = 0, nBricks = 0;
+    const bool inside = x < W && y < y1;
+
+    if (inside) {
+        const kk_vdb_param &p = vdb.vdb_param;
+        const kk_vdb_node *__restrict__ nodePools = vdb.node_pools;
+        const uint32_t *__restrict__ childPools = vdb.child_pools;
+        const T *__restrict__ atlas = static_cast<const T *>(vdb.atlas);
+        const int A = p.vox_per_atlas_brick;
+        const size_t brickVox = static_cast<size_t>(A) * A * A;
+        const bool useDepthBox = p.apron_dep_wid != p.apron_wid;
+        const f3 voxPerVol = {p.vox_per_vol[0], p.vox_per_vol[1], p.vox_per_vol[2]};
+
+        // ---- ray generation, ray_caster_dpbx_vdb.cu:475-501 ----
+        Ray eyeRay;
+        {
+            m4 invProj, w2s;
+            m3 rot;
+            for (int c = 0; c < 4; ++c) {
+                invProj.c[c] = {rp.inv_proj[4 * c], rp.inv_proj[4 * c + 1], rp.inv_proj[4 * c + 2],
+                                rp.inv_proj[4 * c + 3]};
+                w2s.c[c] = {rp.w2s[4 * c], rp.w2s[4 * c + 1], rp.w2s[4 * c + 2], rp.w2s[4 * c + 3]};
+            }
+            for (int c = 0; c < 3; ++c)
+                rot.c[c] = {fr.eye_rot[3 * c], fr.eye_rot[3 * c + 1], fr.eye_rot[3 * c + 2]};
+            f4 tmp;
+            tmp.z = static_cast<float>(W);
+            tmp.w = static_cast<float>(H);
+            tmp.x = (2.f * x + 1.f - tmp.z) / tmp.z;
+            tmp.y = (2.f * y + 1.f - tmp.w) / tmp.w;
+            tmp.z = 1.f;
+            tmp.w = 1.f;
+            tmp = invProj * tmp;
+            eyeRay.dir = {tmp.x, tmp.y, tmp.z};
+            eyeRay.dir = rot * normalize(eyeRay.dir);
+            tmp = {eyeRay.dir.x, eyeRay.dir.y, eyeRay.dir.z, 0.f};
+            tmp = w2s * tmp;
+            eyeRay.dir = normalize(F3(tmp.x, tmp.y, tmp.z));
+            tmp = w2s * f4{fr.eye_pos[0], fr.eye_pos[1], fr.eye_pos[2], 1.f};
+            eyeRay.pos = {tmp.x, tmp.y, tmp.z};
+        }
+
+        f3 rgb = {0.f, 0.f, 0.f};
+        float a = 0.f;
+
+        // ---- rayCastVDB, ray_caster_dpbx_vdb.cu:44-137 ----
+        bool alive = true;
+        float tEnter, tExit;
+        uint32_t maxStepCnt = 0;
+        float step = 0.f;
+        f3 dltPos = {0.f, 0.f, 0.f};
+        HitAABB(eyeRay, AABB{F3(0.f), F3(1.f)}, tEnter, tExit);
+        alive = !(tEnter >= tExit);
+        if (alive) {
+            const float tDlt = tExit - tEnter;
+            const f3 d = tDlt * eyeRay.dir;
+            maxStepCnt = static_cast<uint32_t>(ceilf(
+                rp.sampling_rate * length(d) * gmax(voxPerVol.x, gmax(voxPerVol.y, voxPerVol.z))));
+            eyeRay.pos = eyeRay.pos * voxPerVol;
+            eyeRay.dir = normalize(eyeRay.dir * voxPerVol);
+            HitAABB(eyeRay, AABB{F3(0.f), voxPerVol}, tEnter, tExit);
+            alive = !(tEnter >= tExit);
+        }
+        if (alive) {
+            const float tDlt = tExit - tEnter;
+            step = tDlt / (maxStepCnt - 1);
+            dltPos = step * eyeRay.dir;
+            HitAABB(eyeRay, AABB{F3(0.f), F3(p.vox_per_vdb)}, tEnter, tExit);
+            alive = !(tEnter >= tExit);
+        }
+        if (alive) {
+            // VDBStack, dda.h:13-33: two entries are enough for three levels
+            int lev = p.root_lev + 1;
+            float tExits[2] = {0.f, 0.f};
+            kk_vdb_node nodes[2];
+            nodes[0] = nodes[1] = nodePools[p.node_starts[p.root_lev]];
+            --lev;
+            tExits[lev - 1] = tExit - Eps;
+
+            HDDA3D h;
+            h.sign = {sgn(eyeRay.dir.x), sgn(eyeRay.dir.y), sgn(eyeRay.dir.z)};
+            h.mask = {0, 0, 0};
+            h.tCurr = tEnter + Eps;
+            h.tNext = 0.f;
+            h.Prepare(eyeRay, F3(0.f), p.voxs_per_child[p.root_lev]);
+
+            const float dims0f = p.voxs_per_child[1];
+            // every pass either steps the DDA or descends a level; the guard only bounds a walk fed with
+            // non-finite input
+            for (int guard = 0; guard < (1 << 20) && lev != p.root_lev + 1; ++guard) {
+                const int dimLev = p.dims[lev];
+                if (h.chPos.x < 0 || h.chPos.x >= dimLev || h.chPos.y < 0 || h.chPos.y >= dimLev ||
+                    h.chPos.z < 0 || h.chPos.z >= dimLev)
+                    break;
+                h.Next();
+                const kk_vdb_node &curr = nodes[lev - 1];
+                const int l2 = p.log2_dims[lev];
+                const uint32_t rel = (static_cast<uint32_t>(h.chPos.z) << (l2 << 1)) |
+                                     (static_cast<uint32_t>(h.chPos.y) << l2) |
+                                     static_cast<uint32_t>(h.chPos.x);
+                const uint32_t ch =
+                    childPools[p.child_starts[lev - 1] + curr.child_pool_offs_relative + rel];
+                if (ch != UndefRltIdx) {
+                    if (lev == 1) {
+                        h.tCurr += Eps;
+                        InLeaf param{h.tCurr, h.tNext - Eps};
+                        const kk_vdb_node leaf = nodePools[p.node_starts[0] + ch];
+                        if (COUNT)
+                            ++nBricks;
+                        // ---- inLeafCallback, ray_caster_dpbx_vdb.cu:194-273 ----
+                        bool keepGoing = true;
+                        {
+                            param.tCurr = step * ceilf(param.tCurr / step);
+                            const f3 brickMinVoxPos = toF3(leaf.pos);
+                            f3 posInBrick = eyeRay.pos + param.tCurr * eyeRay.dir - brickMinVoxPos;
+                            const i3 origin = {leaf.brick_pos_in_atlas[0] * A,
+                                               leaf.brick_pos_in_atlas[1] * A,
+                                               leaf.brick_pos_in_atlas[2] * A};
+                            const f3 atlasBrickMinVoxPos = {
+                                static_cast<float>(origin.x + p.apron_dep_wid),
+                                static_cast<float>(origin.y + p.apron_dep_wid),
+                                static_cast<float>(origin.z + p.apron_dep_wid)};
+                            const T *__restrict__ brick = atlas + brickVox * ch;
+                            bool skipped = false;
+                            if (useDepthBox) {
+                                // depthSkip, :139-162
+                                DepthDDA2D d;
+                                if (d.Init(param.tCurr, dims0f, p.min_dep_pos_val_in_brick,
+                                           p.max_dep_pos_val_in_brick, posInBrick, eyeRay)) {
+                                    while (true) {
+                                        const int lx = d.posInBrick.x + p.apron_dep_wid;
+                                        const int ly = d.posInBrick.y + p.apron_dep_wid;
+                                        const int lz = d.posInBrick.z + p.apron_dep_wid;
+                                        T dep = 0; // outside the brick: border
+                                        if (lx >= 0 && lx < A && ly >= 0 && ly < A && lz >= 0 && lz < A)
+                                            dep = brick[(static_cast<size_t>(lz) * A + ly) * A + lx];
+                                        if (static_cast<float>(dep) <= d.dep)
+                                            break;
+                                        if (d.t >= param.tExit) {
+                                            skipped = true;
+                                            break;
+                                        }
+                                        param.tCurr = d.t;
+                                        d.StepNext();
+                                    }
+                                }
+                                if (!skipped) {
+                                    param.tCurr = step * ceilf(param.tCurr / step);
+                                    posInBrick = eyeRay.pos + param.tCurr * eyeRay.dir - brickMinVoxPos;
+                                }
+                            }
+                            if (!skipped) {
+                                while (param.tCurr < param.tExit && !(posInBrick.x < 0.f) &&
+                                       !(posInBrick.x >= dims0f) && !(posInBrick.y < 0.f) &&
+                                       !(posInBrick.y >= dims0f) && !(posInBrick.z < 0.f) &&
+                                       !(posInBrick.z >= dims0f)) {
+                                    f3 samplePos = atlasBrickMinVoxPos + posInBrick;
+                                    const float scalar = sampleBrick<T>(brick, A, origin, samplePos);
+                                    const f4 tfCol = tfLookup(s_tf, scalar);
+                                    f3 tfColRGB = {tfCol.x, tfCol.y, tfCol.z};
+                                    if (COUNT)
+                                        ++nSamples;
+                                    if (rp.use_shading) {
+                                        f3 N;
+                                        samplePos.x += .5f;
+                                        float v0 = sampleBrick<T>(brick, A, origin, samplePos);
+                                        samplePos.x -= 1.f;
+                                        float v1 = sampleBrick<T>(brick, A, origin, samplePos);
+                                        N.x = v1 - v0;
+                                        samplePos.y += .5f;
+                                        v0 = sampleBrick<T>(brick, A, origin, samplePos);
+                                        samplePos.y -= 1.f;
+                                        v1 = sampleBrick<T>(brick, A, origin, samplePos);
+                                        N.y = v1 - v0;
+                                        samplePos.z += .5f;
+                                        v0 = sampleBrick<T>(brick, A, origin, samplePos);
+                                        samplePos.z -= 1.f;
+                                        v1 = sampleBrick<T>(brick, A, origin, samplePos);
+                                        N.z = v1 - v0;
+                                        N = normalize(N);
+                                        if (dot(eyeRay.dir, N) > 0.f)
+                                            N = -N;
+                                        const f3 lightPos = {rp.light_pos[0], rp.light_pos[1], rp.light_pos[2]};
+                                        const f3 lightCol = {rp.light_col[0], rp.light_col[1], rp.light_col[2]};
+                                        const f3 p2lDir = normalize(lightPos - brickMinVoxPos - posInBrick);
+                                        const f3 ambient = rp.ka * tfColRGB;
+                                        const f3 diffuse =
+                                            rp.kd * gmax(0.f, dot(N, p2lDir)) * tfColRGB * lightCol;
+                                        const f3 hfDir = normalize(p2lDir - eyeRay.dir);
+                                        const f3 specular =
+                                            rp.ks * powf(gmax(0.f, dot(N, hfDir)), rp.shiness) * lightCol;
+                                        tfColRGB = {ambient.x + diffuse.x + specular.x,
+                                                    ambient.y + diffuse.y + specular.y,
+                                                    ambient.z + diffuse.z + specular.z};
+                                    }
+                                    rgb = rgb + (1.f - a) * tfCol.w * tfColRGB;
+                                    a = a + (1.f - a) * tfCol.w;
+                                    if (a >= rp.max_alpha) {
+                                        keepGoing = false;
+                                        break;
+                                    }
+                                    param.tCurr += step;
+                                    posInBrick = posInBrick + dltPos;
+                                }
+                            }
+                        }
+                        if (!keepGoing)
+                            break;
+                        h.Step();
+                    } else {
+                        // Push, dda.h:23-27
+                        const float pushedExit = h.tNext - Eps;
+                        --lev;
+                        nodes[lev - 1] = nodePools[p.node_starts[lev] + ch];
+                        tExits[lev - 1] = pushedExit;
+                        h.tCurr += Eps;
+                        h.Prepare(eyeRay, toF3(nodes[lev - 1].pos), p.voxs_per_child[lev]);
+                    }
+                } else
+                    h.Step();
+
+                while (h.tCurr >= tExits[lev - 1]) {
+                    ++lev;
+                    if (lev == p.root_lev + 1)
+                        break;
+                    h.Prepare(eyeRay, toF3(nodes[lev - 1].pos), p.voxs_per_child[lev]);
+                }
+            }
+        }
+
+        // HDRToLDRCorrect + GammaCorrect (include/cg/math.h:75-93), RGBA8 with alpha = opacity
+        rgb = rgb / (rgb + 1.f);
+        rgb.x = powf(rgb.x, 1.f / 2.2f);
+        rgb.y = powf(rgb.y, 1.f / 2.2f);
+        rgb.z = powf(rgb.z, 1.f / 2.2f);
+        uchar4 o;
+        o.x = static_cast<uint8_t>(255.f * rgb.x);
+        o.y = static_cast<uint8_t>(255.f * rgb.y);
+        o.z = static_cast<uint8_t>(255.f * rgb.z);
+        o.w = static_cast<uint8_t>(255.f * a);
+        reinterpret_cast<uchar4 *>(rgba)[static_cast<size_t>(y) * W + x] = o;
+    }
+
+    if (COUNT) {
+        for (int o = 32; o > 0; o >>= 1) {
+            nSamples += __shfl_xor(nSamples, o, 64);
+            nBricks += __shfl_xor(nBricks, o, 64);
+        }
+        if (lane == 0) {
+            atomicAdd(&counters[0], nSamples);
+            atomicAdd(&counters[1], nBricks);
+        }
+    }
+}
+
+template <typename T>
+int launch(const kk_vdb_device_data *h_vdb, const float *d_tf, const kk_dvr_params *h_params,
+           const kk_dvr_frame *h_frame, uint8_t *d_rgba, int width, int height, int y0, int y1,
+           unsigned long long *d_counters, hipStream_t stream) {
+    KK_REQUIRE(h_vdb && d_tf && h_params && h_frame && d_rgba, "null pointer");
+    KK_REQUIRE(h_vdb->node_pools && h_vdb->child_pools && h_vdb->atlas, "VDB arrays missing");
+    KK_REQUIRE(h_vdb->voxel_bytes == sizeof(T), "voxel type does not match the VDB");
+    KK_REQUIRE(h_vdb->vdb_param.root_lev >= 1 && h_vdb->vdb_param.root_lev <= 2, "root level out of range");
+    KK_REQUIRE(width > 0 && height > 0 && y0 >= 0 && y1 <= height && y0 <= y1, "bad image size or rows");
+    if (y0 == y1)
+        return KK_OK;
+    dim3 grid(div_up(width, 16), div_up(y1 - y0, 16));
+    if (d_counters)
+        dvr_kernel<T, true><<<grid, THREADS, 0, stream>>>(*h_vdb, d_tf, *h_params, *h_frame, d_rgba,
+                                                          width, height, y0, y1, d_counters);
+    else
+        dvr_kernel<T, false><<<grid, THREADS, 0, stream>>>(*h_vdb, d_tf, *h_params, *h_frame, d_rgba,
+                                                           width, height, y0, y1, nullptr);
+    KK_LAUNCH_CHECK();
+    return KK_OK;
+}
+
+} // namespace dvr
+} // namespace kk
+
+extern "C" int kk_dvr_render_u8(const kk_vdb_device_data *h_vdb, const float *d_tf,
+                                const kk_dvr_params *h_params, const kk_dvr_frame *h_frame,
+                                uint8_t *d_rgba, int width, int height, int y0, int y1,
+                                unsigned long long *d_counters, void *stream) {
+    return kk::dvr::launch<uint8_t>(h_vdb, d_tf, h_params, h_frame, d_rgba, width, height, y0, y1,
+                                    d_counters, static_cast<hipStream_t>(stream));
+}
+extern "C" int kk_dvr_render_u16(const kk_vdb_device_data *h_vdb, const float *d_tf,
+                                 const kk_dvr_params *h_params, const kk_dvr_frame *h_frame,
+                                 uint8_t *d_rgba, int width, int height, int y0, int y1,
+                                 unsigned long long *d_counters, void *stream) {
+    return kk::dvr::launch<uint16_t>(h_vdb, d_tf, h_params, h_frame, d_rgba, width, height, y0, y1,
+                                     d_counters, static_cast<hipStream_t>(stream));
+}

@@ -1,0 +1,370 @@
+// Depth-Box VDB build: DepthBoxVDB::BuildFrom<T> (src/ray_caster/dpbx_vdb.cu:275-610).
+//   classify   (device) one workgroup per brick of the leaf grid reads its dims0^3 voxels with
+//              row-contiguous loads and decides whether the brick is empty under the transfer function
+//              (dpbx_vdb.cu:345-385, where one thread walks the brick through the texture unit);
+//   plan, wire (host)   tree parameters, node pools sorted by (level, x, y, z), dense child pools, atlas
+//              map (dpbx_vdb.cu:282-338, 387-571). A few thousand nodes: not worth a kernel;
+//   fill_atlas (device) one workgroup per valid brick writes its (dims0 + 2 apronDepWid)^3 atlas voxels
+//              contiguously: volume data inside, depth values on the one-face shell (dpbx_vdb.cu:176-272).
+// Point sampling of the volume (tex3D, cudaFilterModePoint, border addressing) is "voxel at the integer
+// coordinate, 0 outside the volume".
+#include "kk_host.h"
+
+#include <algorithm>
+#include <string.h>
+#include <vector>
+
+namespace kk {
+namespace vdb {
+
+constexpr int THREADS = 256;
+constexpr int MAX_RNGS = 8;
+
+template <typename T> struct Ranges {
+    T lo[MAX_RNGS], hi[MAX_RNGS];
+    uint32_t n;
+};
+
+template <typename T>
+__device__ __forceinline__ T voxelAt(const T *__restrict__ vol, int dx, int dy, int dz, int x, int y,
+                                     int z) {
+    if (x < 0 || y < 0 || z < 0 || x >= dx || y >= dy || z >= dz)
+        return 0;
+    return vol[(static_cast<size_t>(z) * dy + y) * dx + x];
+}
+
+template <typename T> __device__ __forceinline__ uint32_t rangeHits(T v, const Ranges<T> &r) {
+    uint32_t c = 0;
+    for (uint32_t i = 0; i < r.n; ++i)
+        c += (v >= r.lo[i] && v <= r.hi[i]) ? 1u : 0u;
+    return c;
+}
+
+template <typename T>
+__global__ __launch_bounds__(THREADS) void classify_kernel(const T *__restrict__ vol, int dx, int dy,
+                                                           int dz, int log2B, uint32_t lx, uint32_t ly,
+                                                           Ranges<T> rngs,
+                                                           uint32_t *__restrict__ leafValid) {
+    __shared__ uint32_t s_red[THREADS / 64];
+    const uint32_t leaf = blockIdx.x;
+    const uint32_t lz_ = leaf / (lx * ly);
+    const uint32_t ly_ = (leaf - lz_ * lx * ly) / lx;
+    const uint32_t lx_ = leaf - lz_ * lx * ly - ly_ * lx;
+    const int B = 1 << log2B;
+    const int px = lx_ << log2B, py = ly_ << log2B, pz = lz_ << log2B;
+    const uint64_t voxNum = 1ull << (3 * log2B);
+    uint32_t hits = 0;
+    for (uint64_t v = threadIdx.x; v < voxNum; v += THREADS) {
+        const int x = static_cast<int>(v & (B - 1));
+        const int y = static_cast<int>((v >> log2B) & (B - 1));
+        const int z = static_cast<int>(v >> (2 * log2B));
+        hits += rangeHits(voxelAt(vol, dx, dy, dz, px + x, py + y, pz + z), rngs);
+    }
+    for (int o = 32; o > 0; o >>= 1)
+        hits += __shfl_xor(hits, o, 64);
+    if ((threadIdx.x & 63) == 0)
+        s_red[threadIdx.x >> 6] = hits;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t total = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+        leafValid[leaf] = (total == static_cast<uint32_t>(voxNum)) ? 0u : 1u;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(THREADS) void fill_atlas_kernel(const T *__restrict__ vol, int dx, int dy,
+                                                             int dz, const kk_vdb_node *__restrict__ leaves,
+                                                             int B, int apronWid, int apronDepWid,
+                                                             Ranges<T> rngs, T *__restrict__ atlas) {
+    const int A = B + 2 * apronDepWid;
+    const size_t brickVox = static_cast<size_t>(A) * A * A;
+    const kk_vdb_node leaf = leaves[blockIdx.x];
+    T *__restrict__ out = atlas + brickVox * blockIdx.x;
+    const bool depthBox = apronDepWid != apronWid;
+    for (size_t v = threadIdx.x; v < brickVox; v += THREADS) {
+        const int ax = static_cast<int>(v % A);
+        const int ay = static_cast<int>((v / A) % A);
+        const int az = static_cast<int>(v / (static_cast<size_t>(A) * A));
+        int dirX = 0, dirY = 0, dirZ = 0;
+        if (depthBox) {
+            dirX = ax == 0 ? 1 : ax == A - 1 ? -1 : 0;
+            dirY = ay == 0 ? 1 : ay == A - 1 ? -1 : 0;
+            dirZ = az == 0 ? 1 : az == A - 1 ? -1 : 0;
+        }
+        const int faces = (dirX != 0) + (dirY != 0) + (dirZ != 0);
+        T value;
+        if (faces == 0) {
+            value = voxelAt(vol, dx, dy, dz, leaf.pos[0] + ax - apronDepWid, leaf.pos[1] + ay - apronDepWid,
+                            leaf.pos[2] + az - apronDepWid);
+        } else if (faces > 1) {
+            value = 0;
+        } else {
+            // march inwards from the face with a 3 x 3 window until a non-empty voxel shows up
+            int cx = leaf.pos[0] + (dirX == 1 ? 0 : dirX == -1 ? B - 1 : ax - apronDepWid);
+            int cy = leaf.pos[1] + (dirY == 1 ? 0 : dirY == -1 ? B - 1 : ay - apronDepWid);
+            int cz = leaf.pos[2] + (dirZ == 1 ? 0 : dirZ == -1 ? B - 1 : az - apronDepWid);
+            // the two axes spanning the window
+            const int ux = dirX != 0 ? 0 : dirY != 0 ? 0 : 1, uy = dirX != 0 ? 1 : 0, uz = dirY != 0 ? 1 : 0;
+            const int wx = dirX != 0 ? 0 : dirY != 0 ? 1 : 0, wy = dirZ != 0 ? 1 : 0, wz = dirX != 0 ? 1 : 0;
+            int dep;
+            for (dep = 0; dep < B - 1; ++dep) {
+                bool allEmpty = true;
+                for (int t = 0; t < 9 && allEmpty; ++t) {
+                    const int d0 = (t % 3) - 1, d1 = (t / 3) - 1;
+                    const T s = voxelAt(vol, dx, dy, dz, cx + d0 * ux + d1 * wx, cy + d0 * uy + d1 * wy,
+                                        cz + d0 * uz + d1 * wz);
+                    allEmpty = rangeHits(s, rngs) != 0;
+                }
+                if (!allEmpty)
+                    break;
+                cx += dirX;
+                cy += dirY;
+                cz += dirZ;
+            }
+            value = static_cast<T>(dep);
+        }
+        out[v] = value;
+    }
+}
+
+template <typename T> int makeRanges(const T *h, uint32_t n, Ranges<T> &r) {
+    KK_REQUIRE(n <= MAX_RNGS, "too many empty scalar ranges");
+    KK_REQUIRE(n == 0 || h != nullptr, "null pointer");
+    r.n = n;
+    for (uint32_t i = 0; i < n; ++i) {
+        r.lo[i] = h[2 * i];
+        r.hi[i] = h[2 * i + 1];
+    }
+    return KK_OK;
+}
+
+template <typename T>
+int classify(const T *d_volume, uint32_t dx, uint32_t dy, uint32_t dz, uint32_t log2B, const T *h_rngs,
+             uint32_t n, uint32_t *d_leaf_valid, void *stream) {
+    KK_REQUIRE(d_volume && d_leaf_valid, "null pointer");
+    KK_REQUIRE(dx > 0 && dy > 0 && dz > 0, "empty volume");
+    KK_REQUIRE(log2B >= 1 && log2B <= 10, "log2 dimension out of range");
+    Ranges<T> r;
+    int rc = makeRanges(h_rngs, n, r);
+    if (rc != KK_OK)
+        return rc;
+    const uint32_t B = 1u << log2B;
+    const uint32_t lx = (dx + B - 1) / B, ly = (dy + B - 1) / B, lz = (dz + B - 1) / B;
+    classify_kernel<T><<<lx * ly * lz, THREADS, 0, static_cast<hipStream_t>(stream)>>>(
+        d_volume, dx, dy, dz, log2B, lx, ly, r, d_leaf_valid);
+    KK_LAUNCH_CHECK();
+    return KK_OK;
+}
+
+template <typename T>
+int fillAtlas(const T *d_volume, uint32_t dx, uint32_t dy, uint32_t dz, const kk_vdb_plan *plan,
+              const kk_vdb_node *d_node_pools, const T *h_rngs, uint32_t n, T *d_atlas, void *stream) {
+    KK_REQUIRE(d_volume && plan && d_node_pools && d_atlas, "null pointer");
+    KK_REQUIRE(plan->leaf_num > 0, "no leaves");
+    Ranges<T> r;
+    int rc = makeRanges(h_rngs, n, r);
+    if (rc != KK_OK)
+        return rc;
+    const kk_vdb_param &p = plan->param;
+    fill_atlas_kernel<T><<<plan->leaf_num, THREADS, 0, static_cast<hipStream_t>(stream)>>>(
+        d_volume, dx, dy, dz, d_node_pools + p.node_starts[0], p.dims[0], p.apron_wid, p.apron_dep_wid,
+        r, d_atlas);
+    KK_LAUNCH_CHECK();
+    return KK_OK;
+}
+
+// ---- host wiring -------------------------------------------------------------------------------------
+
+struct Coord {
+    int32_t x, y, z;
+    bool operator<(const Coord &o) const {
+        return x != o.x ? x < o.x : y != o.y ? y < o.y : z < o.z;
+    }
+    bool operator==(const Coord &o) const { return x == o.x && y == o.y && z == o.z; }
+};
+
+// Node coordinates of every level, each level sorted by (x, y, z) and unique: level 0 holds the valid
+// leaves in brick units, level l+1 the level-l coordinates divided by dims[l+1].
+static void levelCoords(const kk_vdb_plan &plan, const uint32_t *leafValid,
+                        std::vector<Coord> levels[KK_VDB_MAX_LEVEL_NUM]) {
+    const uint32_t lx = plan.leaf_slots[0], ly = plan.leaf_slots[1], lz = plan.leaf_slots[2];
+    for (uint32_t z = 0; z < lz; ++z)
+        for (uint32_t y = 0; y < ly; ++y)
+            for (uint32_t x = 0; x < lx; ++x)
+                if (leafValid[(static_cast<size_t>(z) * ly + y) * lx + x])
+                    levels[0].push_back({static_cast<int32_t>(x), static_cast<int32_t>(y),
+                                         static_cast<int32_t>(z)});
+    std::sort(levels[0].begin(), levels[0].end());
+    for (int lev = 1; lev <= plan.param.root_lev; ++lev) {
+        const int32_t d = plan.param.dims[lev];
+        for (const Coord &c : levels[lev - 1])
+            levels[lev].push_back({c.x / d, c.y / d, c.z / d});
+        std::sort(levels[lev].begin(), levels[lev].end());
+        levels[lev].erase(std::unique(levels[lev].begin(), levels[lev].end()), levels[lev].end());
+    }
+}
+
+} // namespace vdb
+} // namespace kk
+
+extern "C" int kk_vdb_classify_u8(const uint8_t *d_volume, uint32_t dx, uint32_t dy, uint32_t dz,
+                                  uint32_t log2_dim0, const uint8_t *h_empty_rngs, uint32_t n_rngs,
+                                  uint32_t *d_leaf_valid, void *stream) {
+    return kk::vdb::classify<uint8_t>(d_volume, dx, dy, dz, log2_dim0, h_empty_rngs, n_rngs,
+                                      d_leaf_valid, stream);
+}
+extern "C" int kk_vdb_classify_u16(const uint16_t *d_volume, uint32_t dx, uint32_t dy, uint32_t dz,
+                                   uint32_t log2_dim0, const uint16_t *h_empty_rngs, uint32_t n_rngs,
+                                   uint32_t *d_leaf_valid, void *stream) {
+    return kk::vdb::classify<uint16_t>(d_volume, dx, dy, dz, log2_dim0, h_empty_rngs, n_rngs,
+                                       d_leaf_valid, stream);
+}
+
+extern "C" int kk_vdb_plan_build(uint32_t dx, uint32_t dy, uint32_t dz, const uint8_t log2_dims[3],
+                                 uint8_t apron_wid, int use_depth_box, const uint32_t *h_leaf_valid,
+                                 kk_vdb_plan *out) {
+    using namespace kk;
+    KK_REQUIRE(log2_dims && h_leaf_valid && out, "null pointer");
+    for (int i = 0; i < 3; ++i)
+        KK_REQUIRE(log2_dims[i] > 0 && log2_dims[i] <= 10, "log2Dim > 0 && log2Dim <= MaxLog2Dim should be true");
+    KK_REQUIRE(dx != 0 && dy != 0 && dz != 0, "volume extent should not be zero");
+    memset(out, 0, sizeof(*out));
+    kk_vdb_param &p = out->param;
+    p.apron_wid = apron_wid;
+    p.apron_dep_wid = apron_wid + (use_depth_box ? 1 : 0);
+    for (int lev = 0; lev < KK_VDB_MAX_LEVEL_NUM; ++lev) {
+        p.log2_dims[lev] = log2_dims[lev];
+        p.dims[lev] = 1 << log2_dims[lev];
+    }
+    p.min_dep_pos_val_in_brick = -static_cast<int32_t>(p.apron_dep_wid);
+    p.max_dep_pos_val_in_brick = p.dims[0] - 1 + p.apron_dep_wid;
+    const uint32_t B = p.dims[0];
+    out->leaf_slots[0] = (dx + B - 1) / B;
+    out->leaf_slots[1] = (dy + B - 1) / B;
+    out->leaf_slots[2] = (dz + B - 1) / B;
+
+    // smallest level whose span covers the volume (dpbx_vdb.cu:301-338)
+    uint64_t cover = B;
+    p.voxs_per_child[0] = 1.f;
+    int root = 0;
+    while (cover < dx || cover < dy || cover < dz) {
+        ++root;
+        if (root == KK_VDB_MAX_LEVEL_NUM) {
+            set_error("Current VDB configuration cannot cover %ux%ux%u voxels.", dx, dy, dz);
+            return KK_ERR_INVALID;
+        }
+        p.voxs_per_child[root] = static_cast<float>(cover);
+        cover *= static_cast<uint64_t>(p.dims[root]);
+    }
+    if (root == 0) {
+        set_error("one brick covers the whole %ux%ux%u volume: the tree would have no inner level", dx,
+                  dy, dz);
+        return KK_ERR_INVALID;
+    }
+    p.root_lev = static_cast<uint8_t>(root);
+    p.vox_per_vdb = static_cast<float>(cover);
+    p.vox_per_vol[0] = static_cast<float>(dx);
+    p.vox_per_vol[1] = static_cast<float>(dy);
+    p.vox_per_vol[2] = static_cast<float>(dz);
+
+    std::vector<vdb::Coord> levels[KK_VDB_MAX_LEVEL_NUM];
+    vdb::levelCoords(*out, h_leaf_valid, levels);
+    out->leaf_num = static_cast<uint32_t>(levels[0].size());
+    if (out->leaf_num == 0) {
+        set_error("every brick is empty under the given scalar ranges");
+        return KK_ERR_INVALID;
+    }
+    p.vox_per_atlas_brick = p.dims[0] + 2 * p.apron_dep_wid;
+    p.atlas_brick_per_vdb[0] = out->leaf_slots[0];
+    p.atlas_brick_per_vdb[1] = out->leaf_slots[1];
+    const uint64_t perLayer = static_cast<uint64_t>(out->leaf_slots[0]) * out->leaf_slots[1];
+    p.atlas_brick_per_vdb[2] = static_cast<int32_t>((out->leaf_num + perLayer - 1) / perLayer);
+    out->atlas_map_num = perLayer * p.atlas_brick_per_vdb[2];
+    uint64_t nodes = 0, children = 0;
+    for (int lev = 0; lev <= root; ++lev) {
+        p.node_starts[lev] = nodes;
+        nodes += levels[lev].size();
+        if (lev > 0) {
+            p.child_starts[lev - 1] = children;
+            children += static_cast<uint64_t>(levels[lev].size()) * p.dims[lev] * p.dims[lev] * p.dims[lev];
+        }
+    }
+    out->node_num = nodes;
+    out->child_num = children;
+    const uint64_t A = p.vox_per_atlas_brick;
+    out->atlas_voxels = A * A * A * out->leaf_num;
+    return KK_OK;
+}
+
+extern "C" int kk_vdb_wire(const kk_vdb_plan *plan, const uint32_t *h_leaf_valid,
+                           kk_vdb_node *h_node_pools, uint32_t *h_child_pools,
+                           uint32_t *h_atlas_brick_to_node) {
+    using namespace kk;
+    KK_REQUIRE(plan && h_leaf_valid && h_node_pools && h_child_pools && h_atlas_brick_to_node,
+               "null pointer");
+    const kk_vdb_param &p = plan->param;
+    std::vector<vdb::Coord> levels[KK_VDB_MAX_LEVEL_NUM];
+    vdb::levelCoords(*plan, h_leaf_valid, levels);
+    KK_REQUIRE(levels[0].size() == plan->leaf_num, "validity flags changed since the plan was made");
+    memset(h_node_pools, 0, sizeof(kk_vdb_node) * plan->node_num);
+    for (uint64_t i = 0; i < plan->child_num; ++i)
+        h_child_pools[i] = KK_VDB_UNDEF_RLT_IDX;
+    for (uint64_t i = 0; i < plan->atlas_map_num; ++i)
+        h_atlas_brick_to_node[i] = KK_VDB_UNDEF_RLT_IDX;
+
+    const uint32_t lx = plan->leaf_slots[0];
+    const uint32_t lYxX = lx * plan->leaf_slots[1];
+    for (int lev = 0; lev < p.root_lev; ++lev) {
+        // voxels spanned by one unit of this level's coordinates
+        int64_t unit = 1;
+        for (int l = 0; l <= lev; ++l)
+            unit *= p.dims[l];
+        const std::vector<vdb::Coord> &up = levels[lev + 1];
+        const int L = p.log2_dims[lev + 1];
+        const int32_t d = p.dims[lev + 1];
+        const uint64_t childrenPerNode = static_cast<uint64_t>(d) * d * d;
+        for (uint32_t k = 0; k < levels[lev].size(); ++k) {
+            const vdb::Coord c = levels[lev][k];
+            kk_vdb_node &n = h_node_pools[p.node_starts[lev] + k];
+            n.pos[0] = static_cast<int32_t>(c.x * unit);
+            n.pos[1] = static_cast<int32_t>(c.y * unit);
+            n.pos[2] = static_cast<int32_t>(c.z * unit);
+            if (lev == 0) {
+                n.child_pool_offs_relative = KK_VDB_UNDEF_RLT_IDX;
+                n.brick_pos_in_atlas[2] = k / lYxX;
+                n.brick_pos_in_atlas[1] = (k % lYxX) / lx;
+                n.brick_pos_in_atlas[0] = k % lx;
+                h_atlas_brick_to_node[k] = k; // flat atlas index of brick k is k
+            } else
+                n.child_pool_offs_relative = static_cast<uint64_t>(k) * p.dims[lev] * p.dims[lev] * p.dims[lev];
+            // hook the node into its parent's dense child block
+            const vdb::Coord pc = {c.x / d, c.y / d, c.z / d};
+            const uint64_t parent =
+                (lev + 1 == p.root_lev)
+                    ? 0
+                    : static_cast<uint64_t>(std::lower_bound(up.begin(), up.end(), pc) - up.begin());
+            const uint32_t rx = c.x - pc.x * d, ry = c.y - pc.y * d, rz = c.z - pc.z * d;
+            h_child_pools[p.child_starts[lev] + parent * childrenPerNode +
+                          ((rz << (2 * L)) | (ry << L) | rx)] = k;
+        }
+    }
+    // the root sits last, at the origin, and owns the first child block of its level
+    kk_vdb_node &rootNode = h_node_pools[plan->node_num - 1];
+    memset(&rootNode, 0, sizeof(rootNode));
+    return KK_OK;
+}
+
+extern "C" int kk_vdb_fill_atlas_u8(const uint8_t *d_volume, uint32_t dx, uint32_t dy, uint32_t dz,
+                                    const kk_vdb_plan *plan, const kk_vdb_node *d_node_pools,
+                                    const uint8_t *h_empty_rngs, uint32_t n_rngs, uint8_t *d_atlas,
+                                    void *stream) {
+    return kk::vdb::fillAtlas<uint8_t>(d_volume, dx, dy, dz, plan, d_node_pools, h_empty_rngs, n_rngs,
+                                       d_atlas, stream);
+}
+extern "C" int kk_vdb_fill_atlas_u16(const uint16_t *d_volume, uint32_t dx, uint32_t dy, uint32_t dz,
+                                     const kk_vdb_plan *plan, const kk_vdb_node *d_node_pools,
+                                     const uint16_t *h_empty_rngs, uint32_t n_rngs, uint16_t *d_atlas,
+                                     void *stream) {
+    return kk::vdb::fillAtlas<uint16_t>(d_volume, dx, dy, dz, plan, d_node_pools, h_empty_rngs, n_rngs,
+                                        d_atlas, stream);
+}

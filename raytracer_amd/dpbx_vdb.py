@@ -1,0 +1,159 @@
+"""Host-side mirror of kouek::RayCaster::DepthBoxVDB (include/ray_caster/dpbx_vdb.h:27-143).
+
+BuildFrom keeps the reference's configuration (apronWid, log2Dims, useDepthBox, volume,
+emptyScalarRngs); the CUDA texture argument becomes a `Volume` (linear device buffer + dimensions).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import sys
+
+import numpy as np
+import torch
+
+from . import _lib
+
+NODE_DTYPE = np.dtype([("pos", "<i4", (3,)), ("brickPosInAtlas", "<i4", (3,)),
+                       ("childPoolOffsRelative", "<u8")])
+UNDEF_RLT_IDX = 0xFFFFFFFF
+
+
+class Volume:
+    """Replaces the point-filtered CUDA::Texture of the volume: voxels T[dz][dy][dx], x fastest."""
+
+    def __init__(self, data, device="cuda:0"):
+        if isinstance(data, torch.Tensor):
+            t = data
+            assert t.dtype in (torch.uint8, torch.int16, torch.uint16)
+            self.itemsize = 1 if t.dtype == torch.uint8 else 2
+            self.tensor = t.to(device).contiguous()
+        else:
+            a = np.ascontiguousarray(data)
+            assert a.dtype in (np.uint8, np.uint16) and a.ndim == 3
+            self.itemsize = a.dtype.itemsize
+            self.tensor = torch.from_numpy(a.view(np.uint8 if self.itemsize == 1 else np.int16)).to(device)
+        self.device = torch.device(device)
+        self.dz, self.dy, self.dx = (int(s) for s in self.tensor.shape)
+
+    @property
+    def np_dtype(self):
+        return np.uint8 if self.itemsize == 1 else np.uint16
+
+
+class DepthBoxVDB:
+    MaxLevelNum = 3
+    MaxLog2Dim = 10
+    ErrTag = "[DepthBoxVDB Error]"
+
+    def __init__(self, device="cuda:0", verbose: bool = False):
+        self.device = torch.device(device)
+        self.verbose = verbose
+        self._complete = False
+        self._clear()
+
+    def _clear(self):
+        self.plan = None
+        self.d_node_pools = self.d_child_pools = self.d_atlas_brick_to_node = self.d_atlas = None
+        self.device_data = None
+        self.voxel_bytes = 0
+        self.timings = {}
+
+    def BuildFrom(self, volume: Volume, empty_scalar_rngs, apron_wid: int = 1, log2_dims=(4, 4, 3),
+                  use_depth_box: bool = True) -> None:
+        self._complete = False
+        self._clear()
+        try:
+            self._build(volume, empty_scalar_rngs, apron_wid, log2_dims, use_depth_box)
+        except _lib.KoukeError as e:
+            print(f"{self.ErrTag} {e}", file=sys.stderr)
+            return
+        self._complete = True
+        if self.verbose:
+            print("Build VDB with\n"
+                  f"\tNode pools of size {self.GetNodePoolsSize()}x32\n"
+                  f"\tChild pools of size {self.GetChildPoolsSize()}x4\n"
+                  f"\tMaps from atlas brick to node index of size {self.GetAtlasBrickToNodeIndicesSize()}x4\n"
+                  f"\tAtlas of {self.plan.leaf_num} bricks x {self.plan.param.vox_per_atlas_brick}^3 x {self.voxel_bytes}")
+
+    def IsComplete(self) -> bool:
+        return self._complete
+
+    def GetDeviceData(self):
+        """Host copy of the 176-byte device-data struct (its pointers are device pointers)."""
+        return self.device_data
+
+    def GetNodePoolsSize(self) -> int:
+        return 0 if self.plan is None else int(self.plan.node_num)
+
+    def GetChildPoolsSize(self) -> int:
+        return 0 if self.plan is None else int(self.plan.child_num)
+
+    def GetAtlasBrickToNodeIndicesSize(self) -> int:
+        return 0 if self.plan is None else int(self.plan.atlas_map_num)
+
+    # -- implementation ------------------------------------------------------------------------------
+    def _build(self, vol: Volume, rngs, apron_wid, log2_dims, use_depth_box):
+        l = _lib.lib()
+        dev = self.device
+        sfx = "u8" if vol.itemsize == 1 else "u16"
+        rng = np.ascontiguousarray(np.asarray(rngs, vol.np_dtype).reshape(-1, 2))
+        rng_p = rng.ctypes.data_as(C.c_void_p)
+        l2 = (C.c_uint8 * 3)(*[int(x) for x in log2_dims])
+        for x in log2_dims:
+            if not (0 < int(x) <= self.MaxLog2Dim):
+                raise _lib.KoukeError("log2Dim > 0 && log2Dim <= MaxLog2Dim should be true.")
+        B = 1 << int(log2_dims[0])
+        slots = [(d + B - 1) // B for d in (vol.dx, vol.dy, vol.dz)]
+        n_slots = slots[0] * slots[1] * slots[2]
+        stream = _lib.current_stream_ptr()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        with torch.cuda.device(dev):
+            d_valid = torch.empty(n_slots, dtype=torch.int32, device=dev)
+            ev[0].record()
+            _lib.check(getattr(l, f"kk_vdb_classify_{sfx}")(
+                vol.tensor.data_ptr(), vol.dx, vol.dy, vol.dz, int(log2_dims[0]), rng_p, rng.shape[0],
+                d_valid.data_ptr(), stream), "kk_vdb_classify")
+            ev[1].record()
+            h_valid = d_valid.cpu().numpy().view(np.uint32)
+            plan = _lib.VdbPlan()
+            _lib.check(l.kk_vdb_plan_build(vol.dx, vol.dy, vol.dz, l2, int(apron_wid), int(use_depth_box),
+                                           h_valid.ctypes.data_as(C.c_void_p), C.byref(plan)),
+                       "kk_vdb_plan_build")
+            nodes = np.zeros(int(plan.node_num), NODE_DTYPE)
+            children = np.zeros(int(plan.child_num), np.uint32)
+            amap = np.zeros(int(plan.atlas_map_num), np.uint32)
+            _lib.check(l.kk_vdb_wire(C.byref(plan), h_valid.ctypes.data_as(C.c_void_p),
+                                     nodes.ctypes.data_as(C.c_void_p), children.ctypes.data_as(C.c_void_p),
+                                     amap.ctypes.data_as(C.c_void_p)), "kk_vdb_wire")
+            self.d_node_pools = torch.from_numpy(nodes.view(np.uint8)).to(dev)
+            self.d_child_pools = torch.from_numpy(children.view(np.int32)).to(dev)
+            self.d_atlas_brick_to_node = torch.from_numpy(amap.view(np.int32)).to(dev)
+            self.d_atlas = torch.empty(int(plan.atlas_voxels) * vol.itemsize, dtype=torch.uint8, device=dev)
+            ev[2].record()
+            _lib.check(getattr(l, f"kk_vdb_fill_atlas_{sfx}")(
+                vol.tensor.data_ptr(), vol.dx, vol.dy, vol.dz, C.byref(plan), self.d_node_pools.data_ptr(),
+                rng_p, rng.shape[0], self.d_atlas.data_ptr(), stream), "kk_vdb_fill_atlas")
+            ev[3].record()
+            torch.cuda.synchronize(dev)
+        self.timings = {"classify_ms": ev[0].elapsed_time(ev[1]), "fill_atlas_ms": ev[2].elapsed_time(ev[3])}
+        self.plan, self.voxel_bytes = plan, vol.itemsize
+        self.host_nodes, self.host_children, self.host_atlas_map = nodes, children, amap
+        dd = _lib.VdbDeviceData()
+        dd.node_pools, dd.child_pools = self.d_node_pools.data_ptr(), self.d_child_pools.data_ptr()
+        dd.atlas_brick_to_node_indices = self.d_atlas_brick_to_node.data_ptr()
+        dd.atlas, dd.leaf_num, dd.voxel_bytes = self.d_atlas.data_ptr(), plan.leaf_num, vol.itemsize
+        dd.vdb_param = plan.param
+        self.device_data = dd
+
+    def rebind(self) -> None:
+        """Rewrites the device pointers of the device-data struct (after the arrays were received from
+        another rank)."""
+        dd = self.device_data
+        dd.node_pools, dd.child_pools = self.d_node_pools.data_ptr(), self.d_child_pools.data_ptr()
+        dd.atlas_brick_to_node_indices = self.d_atlas_brick_to_node.data_ptr()
+        dd.atlas = self.d_atlas.data_ptr()
+
+    def atlas_to_host(self) -> np.ndarray:
+        A = int(self.plan.param.vox_per_atlas_brick)
+        a = self.d_atlas.cpu().numpy().view(np.uint8 if self.voxel_bytes == 1 else np.uint16)
+        return a.reshape(int(self.plan.leaf_num), A, A, A)

@@ -1,0 +1,86 @@
+"""Host-side mirror of kouek::RayCaster::RayCaster (include/ray_caster/ray_caster.h:16-89) for the
+Depth-Box VDB path. The CUDA surface becomes a FrameBuffer, the transfer-function texture a float4[256]
+table in device memory."""
+from __future__ import annotations
+
+import ctypes as C
+import sys
+
+import numpy as np
+import torch
+
+from . import _lib
+from .dpbx_vdb import DepthBoxVDB
+from .ray_tracer import FrameBuffer  # noqa: F401  (same headless framebuffer)
+
+
+class TransferFunctionTable:
+    """Replaces the 1-D float4 CUDA texture of the transfer function (app/dvr_dpbx_vdb.cpp:246-269)."""
+
+    def __init__(self, table, device="cuda:0"):
+        t = np.ascontiguousarray(table, np.float32).reshape(256, 4)
+        self.tensor = torch.from_numpy(t).to(device)
+
+
+class RayCaster:
+    ErrTag = "[RayCaster Error]"
+
+    def __init__(self, device="cuda:0"):
+        self.device = torch.device(device)
+        self._params = _lib.DvrParams()
+        self._params.max_alpha = 0.9
+        self._params.sampling_rate = 3.0
+        self._frame = _lib.DvrFrame()
+        self.vdb = None
+        self.tf = None
+
+    @staticmethod
+    def _fill(arr, value):
+        for i, x in enumerate(np.asarray(value, np.float32).reshape(-1)):
+            arr[i] = float(x)
+
+    def SetDepthBoxVDB(self, vdb: DepthBoxVDB):
+        self.vdb = vdb
+
+    def SetTransferFunctionTexture(self, tf: TransferFunctionTable):
+        self.tf = tf
+
+    def SetMaximumAlpha(self, a: float):
+        self._params.max_alpha = float(a)
+
+    def SetSamplingRate(self, r: float):
+        self._params.sampling_rate = float(r)
+
+    def SetWorldToScene(self, w2s):
+        self._fill(self._params.w2s, w2s)
+
+    def SetCameraToWorld(self, eye_pos, eye_rot):
+        self._fill(self._frame.eye_pos, eye_pos)
+        self._fill(self._frame.eye_rot, eye_rot)
+
+    def SetProjection(self, proj):
+        from .data.camera import inverse_projective
+        self._fill(self._params.inv_proj, inverse_projective(proj))
+
+    def SetShading(self, ka, kd, ks, shiness, light_pos_in_volume_space, light_col):
+        p = self._params
+        p.use_shading, p.ka, p.kd, p.ks, p.shiness = 1, float(ka), float(kd), float(ks), float(shiness)
+        self._fill(p.light_pos, light_pos_in_volume_space)
+        self._fill(p.light_col, light_col)
+
+    def UnsetShading(self):
+        self._params.use_shading = 0
+
+    def RenderDepthBoxVDB(self, fb: FrameBuffer, rows=None, counters=None) -> None:
+        """One frame (Scene target) into fb; `rows` = (y0, y1) renders a stripe only."""
+        if self.vdb is None or self.tf is None or not self.vdb.IsComplete():
+            print(f"{self.ErrTag} vdb or tfTex are not set.", file=sys.stderr)
+            return
+        y0, y1 = rows if rows is not None else (0, fb.height)
+        fn = _lib.lib().kk_dvr_render_u8 if self.vdb.voxel_bytes == 1 else _lib.lib().kk_dvr_render_u16
+        with torch.cuda.device(self.device):
+            _lib.check(fn(C.byref(self.vdb.GetDeviceData()), self.tf.tensor.data_ptr(),
+                          C.byref(self._params), C.byref(self._frame), fb.rgba.data_ptr(), fb.width,
+                          fb.height, int(y0), int(y1),
+                          counters.data_ptr() if counters is not None else None,
+                          _lib.current_stream_ptr()), "kk_dvr_render")

@@ -1,0 +1,204 @@
+"""CPU checker of the Depth-Box VDB build and marcher, and the library's host-side wiring against it.
+Pinned by: parameter values derived from src/ray_caster/dpbx_vdb.cu:282-338,388-399 for the README
+data-set shapes, the structural invariants of include/ray_caster/test_options.h:22-78 (every node and
+leaf reached once from the root; the atlas map names the leaf stored in each brick), and the transfer
+function values the reference's own TransferFunction produces for the README tables. The reference
+ships no golden vectors for this path: beyond these, parity is unpinned."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from raytracer_amd import _lib, synthetic as syn
+from raytracer_amd.data import camera as cam
+from vol_util import HEAD_TF, SNAKE_TF, blob_volume, dvr_setup
+
+
+def test_transfer_function_known_answers():
+    assert HEAD_TF.is_complete and SNAKE_TF.is_complete
+    assert HEAD_TF.dat.shape == (256, 4)
+    assert HEAD_TF.empty_scalar_ranges.tolist() == [[0, 49]]
+    assert SNAKE_TF.empty_scalar_ranges.tolist() == [[0, 95]]
+    np.testing.assert_array_equal(
+        HEAD_TF.dat[50], np.array([3.09366063e-4, 2.21108407e-4, 3.22186388e-3, 3.55509037e-5], np.float32))
+    np.testing.assert_array_equal(HEAD_TF.dat[255], np.array([1, 0, 0, 0.0392156877], np.float32))
+    np.testing.assert_array_equal(
+        SNAKE_TF.dat[128], np.array([1, 0.976594448, 0.938785493, 0.0784313828], np.float32))
+    np.testing.assert_array_equal(SNAKE_TF.dat[255], np.array([1, 0, 0, 1], np.float32))
+
+
+def _walk(v):
+    """test_computeNodesAndChildren: breadth-first walk over the child pools."""
+    p = v.param
+    root_lev = int(p["rootLev"])
+    seen = [np.zeros(0)] * 3
+    counts = []
+    for lev in range(root_lev + 1):
+        end = int(p["nodeStarts"][lev + 1]) if lev < root_lev else len(v.nodes)
+        counts.append(end - int(p["nodeStarts"][lev]))
+    seen = [np.zeros(c, np.int32) for c in counts]
+    frontier = [(root_lev, 0)]
+    seen[root_lev][0] += 1
+    while frontier:
+        lev, rel = frontier.pop()
+        if lev == 0:
+            continue
+        node = v.nodes[int(p["nodeStarts"][lev]) + rel]
+        d = int(p["dims"][lev])
+        beg = int(p["childStarts"][lev - 1]) + int(node["childPoolOffsRelative"])
+        block = v.child_pools[beg:beg + d ** 3]
+        L = int(p["log2Dims"][lev])
+        for idx in np.nonzero(block != 0xFFFFFFFF)[0]:
+            ch = int(block[idx])
+            seen[lev - 1][ch] += 1
+            # the child's position agrees with its slot in the parent's block
+            cx, cy, cz = idx & (d - 1), (idx >> L) & (d - 1), idx >> (2 * L)
+            span = int(p["voxsPerChild"][lev])
+            child = v.nodes[int(p["nodeStarts"][lev - 1]) + ch]
+            assert (child["pos"] == node["pos"] + np.array([cx, cy, cz]) * span).all()
+            frontier.append((lev - 1, ch))
+    for lev in range(root_lev + 1):
+        assert (seen[lev] == 1).all(), f"level {lev}: a node is not reached exactly once"
+    return counts
+
+
+def test_head_shape_parameters_and_structure(oracle):
+    vol = syn.head_volume()
+    v = oracle.OracleVDB(vol, (5, 4, 3), 1, True, HEAD_TF.empty_scalar_ranges)
+    p = v.param
+    assert int(p["rootLev"]) == 1 and float(p["voxPerVDB"]) == 512.0
+    assert p["dims"].tolist() == [32, 16, 8] and int(p["apronDepWid"]) == 2
+    assert int(p["voxPerAtlasBrick"]) == 36
+    assert (int(p["minDepPosValInBrick"]), int(p["maxDepPosValInBrick"])) == (-2, 33)
+    assert p["voxsPerChild"].tolist()[:2] == [1.0, 32.0]
+    assert p["voxPerVol"].tolist() == [128.0, 256.0, 256.0]
+    assert p["atlasBrickPerVDB"].tolist()[:2] == [4, 8]
+    counts = _walk(v)
+    assert counts[0] == v.leaf_num and counts[1] == 1
+    # atlas map: brick k holds leaf k, whose brickPosInAtlas flattens back to k
+    for k in range(v.leaf_num):
+        n = v.nodes[k]
+        bx, by, bz = n["brickPosInAtlas"]
+        flat = (bz * p["atlasBrickPerVDB"][1] + by) * p["atlasBrickPerVDB"][0] + bx
+        assert flat == k and v.atlas_brick_to_node[flat] == k
+
+
+def test_kingsnake_shape_parameters(oracle):
+    # only the shape matters here: a thin slab keeps the test small, three levels are still needed
+    vol = np.zeros((40, 1024, 1024), np.uint8)
+    vol[5:30, 500:560, 100:900] = 200
+    v = oracle.OracleVDB(vol, (5, 4, 3), 1, True, SNAKE_TF.empty_scalar_ranges)
+    p = v.param
+    assert int(p["rootLev"]) == 2 and float(p["voxPerVDB"]) == 4096.0
+    assert p["voxsPerChild"].tolist() == [1.0, 32.0, 512.0]
+    counts = _walk(v)
+    assert counts[2] == 1 and counts[0] == v.leaf_num
+
+
+def test_atlas_contents(oracle):
+    vol = blob_volume((72, 80, 96), seed=3)
+    rng = np.array([[0, 40]], np.uint8)
+    v = oracle.OracleVDB(vol, (4, 2, 2), 1, True, rng)
+    p = v.param
+    B, ad = 16, 2
+    A = B + 2 * ad
+    padded = np.zeros((72 + 2 * A, 80 + 2 * A, 96 + 2 * A), np.uint8)
+    padded[A:A + 72, A:A + 80, A:A + 96] = vol
+    for k in (0, v.leaf_num // 2, v.leaf_num - 1):
+        x, y, z = v.nodes[k]["pos"]
+        brick = v.atlas[k]
+        src = padded[A + z - ad:A + z - ad + A, A + y - ad:A + y - ad + A, A + x - ad:A + x - ad + A]
+        # everything but the outer shell is the volume (border 0)
+        np.testing.assert_array_equal(brick[1:-1, 1:-1, 1:-1], src[1:-1, 1:-1, 1:-1])
+        # shell edges and corners are zero
+        assert brick[0, 0, :].max() == 0 and brick[-1, :, -1].max() == 0 and brick[:, 0, 0].max() == 0
+        # one-face shell: depth of the empty run behind it, at most dims0 - 1
+        face = brick[1:-1, 1:-1, 0]
+        assert face.max() <= B - 1
+        empty = src <= 40
+        for (az, ay) in ((5, 7), (A // 2, A // 2), (A - 3, 2)):
+            dep = 0
+            while dep < B - 1:
+                win = empty[az - 1:az + 2, ay - 1:ay + 2, ad + dep]
+                if not win.all():
+                    break
+                dep += 1
+            assert brick[az, ay, 0] == dep
+
+
+def test_rejections_match_reference_error_paths(oracle):
+    vol = blob_volume((40, 40, 40))
+    with pytest.raises(ValueError):
+        oracle.OracleVDB(vol, (0, 4, 3), 1, True, [[0, 10]])      # log2Dim out of range
+    with pytest.raises(ValueError):
+        oracle.OracleVDB(vol, (1, 1, 1), 1, True, [[0, 10]])      # 8 voxels cannot cover 40
+    with pytest.raises(ValueError):
+        oracle.OracleVDB(vol, (6, 4, 3), 1, True, [[0, 10]])      # one brick covers everything
+
+
+@pytest.mark.parametrize("shape,l2,dtype", [((72, 80, 96), (4, 2, 2), np.uint8),
+                                            ((50, 33, 70), (3, 2, 3), np.uint16),
+                                            ((64, 64, 64), (5, 4, 3), np.uint8)])
+def test_library_host_wiring_matches_checker(oracle, shape, l2, dtype):
+    vol = blob_volume(shape, seed=5, dtype=dtype)
+    top = np.iinfo(dtype).max
+    rng = np.array([[0, int(0.16 * top)]], dtype)
+    v = oracle.OracleVDB(vol, l2, 1, True, rng)
+    B = 1 << l2[0]
+    dz, dy, dx = shape
+    slots = [(d + B - 1) // B for d in (dx, dy, dz)]
+    pad = np.zeros((slots[2] * B, slots[1] * B, slots[0] * B), dtype)
+    pad[:dz, :dy, :dx] = vol
+    blocks = pad.reshape(slots[2], B, slots[1], B, slots[0], B)
+    valid = (~((blocks >= rng[0, 0]) & (blocks <= rng[0, 1])).all(axis=(1, 3, 5))).astype(np.uint32)
+    valid = np.ascontiguousarray(valid.reshape(-1))
+    l = _lib.lib()
+    plan = _lib.VdbPlan()
+    l2c = (C.c_uint8 * 3)(*l2)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    _lib.check(l.kk_vdb_plan_build(dx, dy, dz, l2c, 1, 1, vp(valid), C.byref(plan)), "plan")
+    assert plan.leaf_num == v.leaf_num and plan.node_num == len(v.nodes)
+    assert plan.child_num == len(v.child_pools) and plan.atlas_map_num == len(v.atlas_brick_to_node)
+    assert bytes(plan.param)[:124] == v.param.tobytes()[:124]
+    nodes = np.zeros(plan.node_num, oracle.VDB_NODE_DTYPE)
+    children = np.zeros(plan.child_num, np.uint32)
+    amap = np.zeros(plan.atlas_map_num, np.uint32)
+    _lib.check(l.kk_vdb_wire(C.byref(plan), vp(valid), vp(nodes), vp(children), vp(amap)), "wire")
+    np.testing.assert_array_equal(children, v.child_pools)
+    np.testing.assert_array_equal(amap, v.atlas_brick_to_node)
+    np.testing.assert_array_equal(nodes["pos"], v.nodes["pos"])
+    np.testing.assert_array_equal(nodes["childPoolOffsRelative"][:-1], v.nodes["childPoolOffsRelative"][:-1])
+    n_leaf = v.leaf_num
+    np.testing.assert_array_equal(nodes["brickPosInAtlas"][:n_leaf], v.nodes["brickPosInAtlas"][:n_leaf])
+
+
+def test_plan_rejections():
+    l = _lib.lib()
+    plan = _lib.VdbPlan()
+    valid = np.ones(8, np.uint32)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    assert l.kk_vdb_plan_build(40, 40, 40, (C.c_uint8 * 3)(0, 4, 3), 1, 1, vp(valid), C.byref(plan)) == -1
+    assert l.kk_vdb_plan_build(40, 40, 40, (C.c_uint8 * 3)(1, 1, 1), 1, 1, vp(valid), C.byref(plan)) == -1
+    assert b"cannot cover" in l.kk_last_error()
+    assert l.kk_vdb_plan_build(40, 40, 40, (C.c_uint8 * 3)(6, 4, 3), 1, 1, vp(valid), C.byref(plan)) == -1
+    zeros = np.zeros(27, np.uint32)
+    assert l.kk_vdb_plan_build(40, 40, 40, (C.c_uint8 * 3)(4, 2, 2), 1, 1, vp(zeros), C.byref(plan)) == -1
+
+
+def test_oracle_render_sane_and_split_invariant(oracle):
+    vol = syn.head_volume((64, 128, 128))
+    v = oracle.OracleVDB(vol, (4, 3, 3), 1, True, HEAD_TF.empty_scalar_ranges)
+    W, H = 96, 72
+    w2s, c, proj = dvr_setup((64, 128, 128), (2, 1, 1), W, H)
+    inv = cam.inverse_projective(proj)
+    img, ns = oracle.dvr_render(v, HEAD_TF.dat, w2s, inv, c.pos, c.rotation(), W, H)
+    assert ns > 10_000 and img[..., 3].max() > 100 and img[0, 0, 3] == 0
+    img2 = np.zeros_like(img)
+    oracle.dvr_render(v, HEAD_TF.dat, w2s, inv, c.pos, c.rotation(), W, H, rows=(0, 30), rgba=img2)
+    oracle.dvr_render(v, HEAD_TF.dat, w2s, inv, c.pos, c.rotation(), W, H, rows=(30, H), rgba=img2)
+    assert img.tobytes() == img2.tobytes()
+    # without the depth boxes the picture is the same up to the rays that start inside a skipped shell
+    v2 = oracle.OracleVDB(vol, (4, 3, 3), 1, False, HEAD_TF.empty_scalar_ranges)
+    img3, ns3 = oracle.dvr_render(v2, HEAD_TF.dat, w2s, inv, c.pos, c.rotation(), W, H)
+    assert ns3 >= ns
+    assert np.abs(img.astype(int) - img3.astype(int)).max() <= 2
