@@ -129,6 +129,11 @@ def main():
     ms_per_step = wall * 1e3 / K
     value = world * R / (ms_per_step * 1e-3) / 1e6
 
+    dvr = None
+    if not args.no_dvr:
+        from raytracer_amd import bench_dvr
+        dvr = bench_dvr.run(dev, world, rank, dist, with_cpu=not args.no_cpu)
+
     if rank != 0:
         if dist:
             dist.destroy_process_group()
@@ -205,12 +210,9 @@ def main():
                                     ref["internalNodes"].tobytes())}
 
     # ---- volume path (reported beside the headline value) -------------------------------------------
-    if not args.no_dvr:
-        try:
-            from raytracer_amd import bench_dvr
-            out["dvr"] = bench_dvr.run(dev, world, rank)
-        except ImportError:
-            pass
+    if dvr:
+        out["dvr"] = dvr
+        out["dvr_fps_4k"] = dvr["fps"]
 
     print(json.dumps(out))
     if dist:

@@ -342,6 +342,17 @@ int kk_dvr_render_u16(const kk_vdb_device_data *h_vdb, const float *d_tf,
                       const kk_dvr_params *h_params, const kk_dvr_frame *h_frame, uint8_t *d_rgba,
                       int width, int height, int y0, int y1, unsigned long long *d_counters,
                       void *stream);
+/* The same frame restricted to the 16-row stripes stripe_first, stripe_first + stripe_stride, ... of
+ * the image (stripe s = rows [16 s, 16 s + 16)): the share of one GPU when the image is dealt out to
+ * several in round-robin stripes. No counterpart in the reference, which renders on one GPU. */
+int kk_dvr_render_stripes_u8(const kk_vdb_device_data *h_vdb, const float *d_tf,
+                             const kk_dvr_params *h_params, const kk_dvr_frame *h_frame,
+                             uint8_t *d_rgba, int width, int height, int stripe_first,
+                             int stripe_stride, unsigned long long *d_counters, void *stream);
+int kk_dvr_render_stripes_u16(const kk_vdb_device_data *h_vdb, const float *d_tf,
+                              const kk_dvr_params *h_params, const kk_dvr_frame *h_frame,
+                              uint8_t *d_rgba, int width, int height, int stripe_first,
+                              int stripe_stride, unsigned long long *d_counters, void *stream);
 
 #ifdef __cplusplus
 }

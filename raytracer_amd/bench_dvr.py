@@ -1,0 +1,147 @@
+"""DVR leg of the benchmark: Kingsnake-shaped 1024 x 1024 x 795 uint8 volume at 3840 x 2160, README
+Kingsnake transfer function, log2Dims {5,4,3}, sampling rate 3, maxAlpha 0.9, depth boxes on; frames of
+the reference's own perf orbit (0.5 degrees per frame, app/dvr_dpbx_vdb.cpp:349-368). With several
+ranks the VDB is built on rank 0 and broadcast, each rank renders its round-robin 16-row stripes and the
+stripes are gathered to rank 0 once per frame."""
+from __future__ import annotations
+
+import os
+import time
+
+import numpy as np
+import torch
+
+from . import synthetic as syn
+from .data import camera as cam
+from .data.transfer_function import README_KINGSNAKE_TF, TransferFunction
+from .dpbx_vdb import DepthBoxVDB, Volume
+from .ray_caster import FrameBuffer, RayCaster, TransferFunctionTable
+
+HBM_PEAK_GBPS = 8000.0
+
+
+def run(dev: str, world: int, rank: int, dist=None, frames: int = 120, warmup: int = 8,
+        dim=(1024, 1024, 795), size=(3840, 2160), cpu_rows: int = 24, with_cpu: bool = True) -> dict:
+    tf = TransferFunction(README_KINGSNAKE_TF)
+    W, H = size
+    vdb = DepthBoxVDB(dev)
+    build = {}
+    vol_t = None
+    if rank == 0:
+        vol_t = syn.kingsnake_volume_torch(dim, dev)
+        t0 = time.perf_counter()
+        vdb.BuildFrom(Volume(vol_t, dev), tf.empty_scalar_ranges, apron_wid=1, log2_dims=(5, 4, 3),
+                      use_depth_box=True)
+        torch.cuda.synchronize()
+        assert vdb.IsComplete(), "VDB build failed"
+        build = {"total_ms": round((time.perf_counter() - t0) * 1e3, 2),
+                 "classify_ms": round(vdb.timings["classify_ms"], 3),
+                 "fill_atlas_ms": round(vdb.timings["fill_atlas_ms"], 3),
+                 "leaf_bricks": int(vdb.plan.leaf_num),
+                 "leaf_slots": int(np.prod(list(vdb.plan.leaf_slots)))}
+        vol_bytes = dim[0] * dim[1] * dim[2]
+        build["classify_GBps"] = round(vol_bytes / (vdb.timings["classify_ms"] * 1e-3) / 1e9, 1)
+    bcast_ms = None
+    if world > 1:
+        from .multi_gpu import broadcast_vdb
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        broadcast_vdb(vdb, src=0)
+        torch.cuda.synchronize()
+        dist.barrier()
+        bcast_ms = (time.perf_counter() - t0) * 1e3
+
+    scales = cam.volume_scales((1, 1, 1), dim)
+    caster = RayCaster(dev)
+    caster.SetWorldToScene(cam.world_to_scene(scales))
+    caster.SetDepthBoxVDB(vdb)
+    caster.SetTransferFunctionTexture(TransferFunctionTable(tf.dat, dev))
+    proj = cam.perspective_fov(cam.radians(90.0), W, H, 1.0, 3.0)
+    caster.SetProjection(proj)
+    c = cam.FPSCamera((0, 0, float(max(scales))), (0, 0, 0))
+    # the orbit's camera poses, computed once (host work of the reference's frame loop)
+    poses = []
+    for _ in range(warmup + frames):
+        c.Revolve(cam._c("sqrtf", cam._dot(c.pos, c.pos)), 0.5, 0.0)
+        poses.append((c.pos.copy(), c.rotation().copy()))
+    fb = FrameBuffer(W, H, dev)
+    scratch = {}
+
+    def frame(i):
+        caster.SetCameraToWorld(*poses[i])
+        if world > 1:
+            from .multi_gpu import gather_stripes
+            caster.RenderDepthBoxVDB(fb, stripes=(rank, world))
+            gather_stripes(fb.rgba, world, rank, 0, scratch)
+        else:
+            caster.RenderDepthBoxVDB(fb)
+
+    for i in range(warmup):
+        frame(i)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for i in range(warmup, warmup + frames):
+        frame(i)
+    ev1.record()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    wall = time.perf_counter() - t0
+    if dist:
+        tt = torch.tensor([wall], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        wall = float(tt.item())
+    if rank != 0:
+        return {}
+    out = {"workload": f"Kingsnake-shape {dim[0]}x{dim[1]}x{dim[2]} uint8, {W}x{H}, orbit 0.5 deg/frame",
+           "fps": round(frames / wall, 2), "ms_per_frame": round(wall * 1e3 / frames, 4), "frames": frames,
+           "n_gpus": world, "vdb_build": build}
+    if bcast_ms is not None:
+        out["vdb_broadcast_ms"] = round(bcast_ms, 3)
+    if world == 1:
+        # work counters of one frame: samples taken and bricks entered
+        counters = torch.zeros(2, dtype=torch.int64, device=dev)
+        caster.SetCameraToWorld(*poses[warmup])
+        caster.RenderDepthBoxVDB(fb, counters=counters)
+        torch.cuda.synchronize()
+        ns, nb = int(counters[0]), int(counters[1])
+        kernel_ms = ev0.elapsed_time(ev1) / frames
+        # 8 voxel bytes + 2 table entries (32 B, LDS) per sample from cache; compulsory HBM traffic is
+        # the distinct bricks touched plus the 4 B per pixel written
+        out.update({"samples_per_frame": ns, "brick_entries_per_frame": nb,
+                    "Gsamples_per_s": round(ns / (kernel_ms * 1e-3) / 1e9, 3),
+                    "voxel_fetch_GBps": round(8 * ns / (kernel_ms * 1e-3) / 1e9, 1),
+                    "compulsory_bytes_per_frame": int(vdb.plan.atlas_voxels) + 4 * W * H,
+                    "compulsory_frac_of_hbm_peak": round(
+                        (int(vdb.plan.atlas_voxels) + 4 * W * H) / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5)})
+        if with_cpu:
+            from oracle import kkoracle as ko
+            cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or (os.cpu_count() or 1)
+            vol_h = vol_t.cpu().numpy()
+            t0 = time.perf_counter()
+            ref = ko.OracleVDB(vol_h, (5, 4, 3), 1, True, tf.empty_scalar_ranges)
+            cpu_build_s = time.perf_counter() - t0
+            y0 = H // 2 - cpu_rows // 2
+            pos, rot = poses[warmup]
+            t0 = time.perf_counter()
+            want, cpu_ns = ko.dvr_render(ref, tf.dat, cam.world_to_scene(scales),
+                                         cam.inverse_projective(proj), pos, rot, W, H,
+                                         rows=(y0, y0 + cpu_rows))
+            cpu_s = time.perf_counter() - t0
+            got = fb.ReadBack()[y0:y0 + cpu_rows]
+            d = np.abs(got.astype(int) - want[y0:y0 + cpu_rows].astype(int))
+            out["cpu_baseline"] = {"fps_equivalent": round(1.0 / (cpu_s * H / cpu_rows), 4),
+                                   "unit": "fps", "cores": cores, "kind": "port",
+                                   "sample": f"{cpu_rows} centre rows of one {W}x{H} frame ({cpu_ns} samples)",
+                                   "vdb_build_ms": round(cpu_build_s * 1e3, 1)}
+            out["parity_vs_cpu"] = {"rows": cpu_rows, "max_level_diff": int(d.max()),
+                                    "frac_pixels_differing": float((d.max(axis=2) > 0).mean()),
+                                    "alpha_equal": bool((d[..., 3] == 0).all()),
+                                    "vdb_bit_exact": bool(np.array_equal(vdb.atlas_to_host(), ref.atlas) and
+                                                          np.array_equal(vdb.host_children, ref.child_pools))}
+    return out

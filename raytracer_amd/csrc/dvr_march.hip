@@ -185,7 +185,8 @@ __global__ __launch_bounds__(THREADS) void dvr_kernel(const kk_vdb_device_data v
                                                       const float *__restrict__ tf,
                                                       const kk_dvr_params rp, const kk_dvr_frame fr,
                                                       uint8_t *__restrict__ rgba, int W, int H, int y0,
-                                                      int y1, unsigned long long *counters) {
+                                                      int y1, int stripeFirst, int stripeStride,
+                                                      unsigned long long *counters) {
     __shared__ f4 s_tf[256];
     const int tid = threadIdx.x;
     s_tf[tid] = reinterpret_cast<const f4 *>(tf)[tid];
@@ -194,7 +195,9 @@ __global__ __launch_bounds__(THREADS) void dvr_kernel(const kk_vdb_device_data v
     // 16 x 16 pixel block = 2 x 2 waves of 8 x 8 pixels
     const int lane = tid & 63, wave = tid >> 6;
     const int x = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
-    const int y = y0 + blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
+    // block row blockIdx.y renders the 16-row stripe number stripeFirst + blockIdx.y * stripeStride
+    const int y = y0 + (stripeFirst + static_cast<int>(blockIdx.y) * stripeStride) * 16 + (wave >> 1) * 8 +
+                  (lane >> 3);
     unsigned long long nSamples = 0, nBricks = 0;
     const bool inside = x < W && y < y1;
 
@@ -453,21 +456,25 @@ __global__ __launch_bounds__(THREADS) void dvr_kernel(const kk_vdb_device_data v
 template <typename T>
 int launch(const kk_vdb_device_data *h_vdb, const float *d_tf, const kk_dvr_params *h_params,
            const kk_dvr_frame *h_frame, uint8_t *d_rgba, int width, int height, int y0, int y1,
-           unsigned long long *d_counters, hipStream_t stream) {
+           int stripeFirst, int stripeStride, unsigned long long *d_counters, hipStream_t stream) {
     KK_REQUIRE(h_vdb && d_tf && h_params && h_frame && d_rgba, "null pointer");
     KK_REQUIRE(h_vdb->node_pools && h_vdb->child_pools && h_vdb->atlas, "VDB arrays missing");
     KK_REQUIRE(h_vdb->voxel_bytes == sizeof(T), "voxel type does not match the VDB");
     KK_REQUIRE(h_vdb->vdb_param.root_lev >= 1 && h_vdb->vdb_param.root_lev <= 2, "root level out of range");
     KK_REQUIRE(width > 0 && height > 0 && y0 >= 0 && y1 <= height && y0 <= y1, "bad image size or rows");
-    if (y0 == y1)
+    KK_REQUIRE(stripeStride >= 1 && stripeFirst >= 0, "bad stripe selection");
+    const int stripes = static_cast<int>(div_up(y1 - y0, 16));
+    if (y0 == y1 || stripeFirst >= stripes)
         return KK_OK;
-    dim3 grid(div_up(width, 16), div_up(y1 - y0, 16));
+    dim3 grid(div_up(width, 16), div_up(stripes - stripeFirst, stripeStride));
     if (d_counters)
         dvr_kernel<T, true><<<grid, THREADS, 0, stream>>>(*h_vdb, d_tf, *h_params, *h_frame, d_rgba,
-                                                          width, height, y0, y1, d_counters);
+                                                          width, height, y0, y1, stripeFirst,
+                                                          stripeStride, d_counters);
     else
         dvr_kernel<T, false><<<grid, THREADS, 0, stream>>>(*h_vdb, d_tf, *h_params, *h_frame, d_rgba,
-                                                           width, height, y0, y1, nullptr);
+                                                           width, height, y0, y1, stripeFirst,
+                                                           stripeStride, nullptr);
     KK_LAUNCH_CHECK();
     return KK_OK;
 }
@@ -479,13 +486,31 @@ extern "C" int kk_dvr_render_u8(const kk_vdb_device_data *h_vdb, const float *d_
                                 const kk_dvr_params *h_params, const kk_dvr_frame *h_frame,
                                 uint8_t *d_rgba, int width, int height, int y0, int y1,
                                 unsigned long long *d_counters, void *stream) {
-    return kk::dvr::launch<uint8_t>(h_vdb, d_tf, h_params, h_frame, d_rgba, width, height, y0, y1,
+    return kk::dvr::launch<uint8_t>(h_vdb, d_tf, h_params, h_frame, d_rgba, width, height, y0, y1, 0, 1,
                                     d_counters, static_cast<hipStream_t>(stream));
 }
 extern "C" int kk_dvr_render_u16(const kk_vdb_device_data *h_vdb, const float *d_tf,
                                  const kk_dvr_params *h_params, const kk_dvr_frame *h_frame,
                                  uint8_t *d_rgba, int width, int height, int y0, int y1,
                                  unsigned long long *d_counters, void *stream) {
-    return kk::dvr::launch<uint16_t>(h_vdb, d_tf, h_params, h_frame, d_rgba, width, height, y0, y1,
-                                     d_counters, static_cast<hipStream_t>(stream));
+    return kk::dvr::launch<uint16_t>(h_vdb, d_tf, h_params, h_frame, d_rgba, width, height, y0, y1, 0,
+                                     1, d_counters, static_cast<hipStream_t>(stream));
+}
+extern "C" int kk_dvr_render_stripes_u8(const kk_vdb_device_data *h_vdb, const float *d_tf,
+                                        const kk_dvr_params *h_params, const kk_dvr_frame *h_frame,
+                                        uint8_t *d_rgba, int width, int height, int stripe_first,
+                                        int stripe_stride, unsigned long long *d_counters,
+                                        void *stream) {
+    return kk::dvr::launch<uint8_t>(h_vdb, d_tf, h_params, h_frame, d_rgba, width, height, 0, height,
+                                    stripe_first, stripe_stride, d_counters,
+                                    static_cast<hipStream_t>(stream));
+}
+extern "C" int kk_dvr_render_stripes_u16(const kk_vdb_device_data *h_vdb, const float *d_tf,
+                                         const kk_dvr_params *h_params, const kk_dvr_frame *h_frame,
+                                         uint8_t *d_rgba, int width, int height, int stripe_first,
+                                         int stripe_stride, unsigned long long *d_counters,
+                                         void *stream) {
+    return kk::dvr::launch<uint16_t>(h_vdb, d_tf, h_params, h_frame, d_rgba, width, height, 0, height,
+                                     stripe_first, stripe_stride, d_counters,
+                                     static_cast<hipStream_t>(stream));
 }

@@ -70,3 +70,76 @@ def split_range(total: int, world: int, rank: int):
     base, rem = divmod(total, world)
     begin = rank * base + min(rank, rem)
     return begin, begin + base + (1 if rank < rem else 0)
+
+
+# ---- volume path ---------------------------------------------------------------------------------------
+
+def broadcast_vdb(vdb, src: int = 0) -> None:
+    """Broadcasts a built Depth-Box VDB: the 176-byte plan, node pools, child pools, atlas map and the
+    brick atlas; every rank then points its device-data struct at its own copies."""
+    from .dpbx_vdb import DepthBoxVDB  # noqa: F401
+    rank = dist.get_rank()
+    dev = vdb.device
+    plan_bytes = torch.zeros(C.sizeof(_lib.VdbPlan) + 8, dtype=torch.uint8, device=dev)
+    if rank == src:
+        raw = bytes(vdb.plan) + int(vdb.voxel_bytes).to_bytes(8, "little")
+        plan_bytes = torch.from_numpy(np.frombuffer(raw, np.uint8).copy()).to(dev)
+    dist.broadcast(plan_bytes, src=src)
+    if rank != src:
+        raw = plan_bytes.cpu().numpy().tobytes()
+        vdb.plan = _lib.VdbPlan.from_buffer_copy(raw[:C.sizeof(_lib.VdbPlan)])
+        vdb.voxel_bytes = int.from_bytes(raw[C.sizeof(_lib.VdbPlan):], "little")
+        p = vdb.plan
+        vdb.d_node_pools = torch.empty(int(p.node_num) * 32, dtype=torch.uint8, device=dev)
+        vdb.d_child_pools = torch.empty(int(p.child_num), dtype=torch.int32, device=dev)
+        vdb.d_atlas_brick_to_node = torch.empty(int(p.atlas_map_num), dtype=torch.int32, device=dev)
+        vdb.d_atlas = torch.empty(int(p.atlas_voxels) * vdb.voxel_bytes, dtype=torch.uint8, device=dev)
+    for t in (vdb.d_node_pools, vdb.d_child_pools, vdb.d_atlas_brick_to_node, vdb.d_atlas):
+        dist.broadcast(t, src=src)
+    if rank != src:
+        dd = _lib.VdbDeviceData()
+        dd.leaf_num, dd.voxel_bytes, dd.vdb_param = vdb.plan.leaf_num, vdb.voxel_bytes, vdb.plan.param
+        vdb.device_data = dd
+        vdb.rebind()
+        vdb._complete = True
+
+
+STRIPE_ROWS = 16
+
+
+def stripes_of(height: int, world: int, rank: int):
+    """Indices of the 16-row stripes rank `rank` renders: round-robin, so that empty borders and the
+    dense centre of the picture are spread over all ranks."""
+    n = (height + STRIPE_ROWS - 1) // STRIPE_ROWS
+    return list(range(rank, n, world))
+
+
+def gather_stripes(rgba: torch.Tensor, world: int, rank: int, dst: int = 0, scratch=None):
+    """Gathers every rank's stripes of an [H, W, 4] uint8 frame into rank `dst`'s frame. One collective
+    per frame; ranks with one stripe fewer send a padded block."""
+    H, W = rgba.shape[0], rgba.shape[1]
+    n = (H + STRIPE_ROWS - 1) // STRIPE_ROWS
+    per = (n + world - 1) // world
+    pad_h = n * STRIPE_ROWS
+    if scratch is None:
+        scratch = {}
+    key = (H, W, world, rgba.device)
+    if scratch.get("key") != key:
+        scratch["key"] = key
+        scratch["send"] = torch.zeros((per, STRIPE_ROWS, W, 4), dtype=torch.uint8, device=rgba.device)
+        scratch["recv"] = ([torch.zeros((per, STRIPE_ROWS, W, 4), dtype=torch.uint8, device=rgba.device)
+                            for _ in range(world)] if rank == dst else None)
+        scratch["padded"] = torch.zeros((pad_h, W, 4), dtype=torch.uint8, device=rgba.device)
+    send = scratch["send"]
+    mine = stripes_of(H, world, rank)
+    padded = scratch["padded"]
+    padded[:H] = rgba
+    view = padded.view(n, STRIPE_ROWS, W, 4)
+    send[:len(mine)] = view[rank::world]
+    dist.gather(send, scratch["recv"], dst=dst)
+    if rank == dst:
+        for r in range(world):
+            cnt = len(range(r, n, world))
+            view[r::world] = scratch["recv"][r][:cnt]
+        rgba.copy_(padded[:H])
+    return scratch

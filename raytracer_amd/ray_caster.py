@@ -71,16 +71,21 @@ class RayCaster:
     def UnsetShading(self):
         self._params.use_shading = 0
 
-    def RenderDepthBoxVDB(self, fb: FrameBuffer, rows=None, counters=None) -> None:
-        """One frame (Scene target) into fb; `rows` = (y0, y1) renders a stripe only."""
+    def RenderDepthBoxVDB(self, fb: FrameBuffer, rows=None, counters=None, stripes=None) -> None:
+        """One frame (Scene target) into fb. `rows` = (y0, y1) renders those rows only; `stripes` =
+        (first, stride) renders the 16-row stripes first, first + stride, ... (one GPU's share)."""
         if self.vdb is None or self.tf is None or not self.vdb.IsComplete():
             print(f"{self.ErrTag} vdb or tfTex are not set.", file=sys.stderr)
             return
-        y0, y1 = rows if rows is not None else (0, fb.height)
-        fn = _lib.lib().kk_dvr_render_u8 if self.vdb.voxel_bytes == 1 else _lib.lib().kk_dvr_render_u16
+        sfx = "u8" if self.vdb.voxel_bytes == 1 else "u16"
+        if stripes is not None:
+            fn, a, b = getattr(_lib.lib(), f"kk_dvr_render_stripes_{sfx}"), stripes[0], stripes[1]
+        else:
+            fn = getattr(_lib.lib(), f"kk_dvr_render_{sfx}")
+            a, b = rows if rows is not None else (0, fb.height)
         with torch.cuda.device(self.device):
             _lib.check(fn(C.byref(self.vdb.GetDeviceData()), self.tf.tensor.data_ptr(),
                           C.byref(self._params), C.byref(self._frame), fb.rgba.data_ptr(), fb.width,
-                          fb.height, int(y0), int(y1),
+                          fb.height, int(a), int(b),
                           counters.data_ptr() if counters is not None else None,
                           _lib.current_stream_ptr()), "kk_dvr_render")

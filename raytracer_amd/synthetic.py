@@ -151,3 +151,38 @@ def kingsnake_volume(dim=(1024, 1024, 795), seed: int = SEED_SNAKE, turns: float
         tube = 130.0 + 125.0 * prof * prof * (3.0 - 2.0 * prof)
         out[z] = np.where(d < tube_radius, tube, bg).astype(np.uint8)
     return out
+
+
+def kingsnake_volume_torch(dim=(1024, 1024, 795), device="cuda:0", seed: int = SEED_SNAKE,
+                           turns: float = 6.0, coil_radius: float = 0.30, tube_radius: float = 0.045,
+                           slab: int = 32):
+    """The Kingsnake-shaped volume generated on the GPU, slab by slab (833 MB at full size is not a
+    fixture): same helical tube as kingsnake_volume; the background noise comes from a 32-bit integer
+    hash of the voxel index instead of splitmix64. Returns a uint8 torch tensor [dz, dy, dx]."""
+    import torch
+    dx, dy, dz = dim
+    out = torch.empty((dz, dy, dx), dtype=torch.uint8, device=device)
+    xs = torch.arange(dx, device=device, dtype=torch.float32)
+    ys = torch.arange(dy, device=device, dtype=torch.float32)
+    PX = ((xs + 0.5) / dx - 0.5)[None, None, :]
+    PY = ((ys + 0.5) / dy - 0.5)[None, :, None]
+    ix = torch.arange(dx, device=device, dtype=torch.int64)[None, None, :]
+    iy = torch.arange(dy, device=device, dtype=torch.int64)[None, :, None]
+    for z0 in range(0, dz, slab):
+        z1 = min(dz, z0 + slab)
+        zz = torch.arange(z0, z1, device=device, dtype=torch.float32)
+        ang = (2.0 * np.pi * turns) * ((zz + 0.5) / dz)
+        cx = (coil_radius * torch.cos(ang))[:, None, None]
+        cy = (coil_radius * torch.sin(ang))[:, None, None]
+        d = torch.sqrt((PX - cx) ** 2 + (PY - cy) ** 2)
+        iz = torch.arange(z0, z1, device=device, dtype=torch.int64)[:, None, None]
+        h = (ix * 73856093 + iy * 19349663 + iz * 83492791 + seed) & 0xFFFFFFFF
+        h = ((h ^ (h >> 15)) * 0x85EBCA77) & 0xFFFFFFFF
+        h = ((h ^ (h >> 13)) * 0xC2B2AE3D) & 0xFFFFFFFF
+        h = h ^ (h >> 16)
+        noise = (h >> 8).to(torch.float32) * (1.0 / 16777216.0)
+        bg = 30.0 + 40.0 * noise
+        prof = torch.clamp(1.0 - d / tube_radius, 0.0, 1.0)
+        tube = 130.0 + 125.0 * prof * prof * (3.0 - 2.0 * prof)
+        out[z0:z1] = torch.where(d < tube_radius, tube, bg).to(torch.uint8)
+    return out
