@@ -1,0 +1,140 @@
+// kouek::RayCaster::DepthBoxVDB with the reference's public interface (reference
+// include/ray_caster/dpbx_vdb.h:27-143, src/ray_caster/dpbx_vdb.cu:275-637). The point-filtered volume
+// texture of InputVolumeAndConfiguration becomes a HIP::Volume<T>.
+#ifndef KOUEK_RAY_CASTER_DPBX_VDB_H
+#define KOUEK_RAY_CASTER_DPBX_VDB_H
+
+#include <array>
+#include <limits>
+#include <string_view>
+#include <type_traits>
+#include <vector>
+
+#include "../hip/device.h"
+
+namespace kouek {
+namespace RayCaster {
+
+class DepthBoxVDB : Noncopyable {
+  public:
+    static constexpr auto MaxLevelNum = uint8_t(3);
+    static constexpr auto MaxLog2Dim = uint8_t(10);
+    using IndexTy = uint64_t;
+    using RelativeIndexTy = uint32_t;
+    using CoordValTy = int32_t;
+    static constexpr auto UndefRltIdx = std::numeric_limits<RelativeIndexTy>::max();
+
+    using VDBParameter = kk_vdb_param;  // same layout as the reference's struct
+    using Node = kk_vdb_node;
+    using DeviceData = kk_vdb_device_data;
+
+  private:
+    bool isComplete = false;
+    HIP::DeviceBuffer<Node> d_nodePools;
+    HIP::DeviceBuffer<RelativeIndexTy> d_childPools;
+    HIP::DeviceBuffer<RelativeIndexTy> d_atlasBrickToNodeIndices;
+    HIP::DeviceBuffer<uint8_t> d_atlas;
+    DeviceData deviceDat{};
+    HIP::DeviceBuffer<DeviceData> d_deviceDat;
+    static constexpr std::string_view ErrTag = "[DepthBoxVDB Error]";
+
+    template <typename T> struct Fn;
+
+  public:
+    template <typename T, typename Vec2T = vec2_of<T>> struct InputVolumeAndConfiguration {
+        static_assert(std::is_same_v<T, uint8_t> || std::is_same_v<T, uint16_t>,
+                      "T as voxel type is not implemented.");
+        uint8_t apronWid = 1;
+        std::array<uint8_t, MaxLevelNum> log2Dims = {4, 4, 3};
+        bool useDepthBox = true;
+        const HIP::Volume<T> &volTex;
+        const std::vector<Vec2T> &emptyScalarRngs;
+    };
+
+    template <typename T, typename Vec2T = vec2_of<T>>
+    void BuildFrom(const InputVolumeAndConfiguration<T, Vec2T> &cfg) {
+        isComplete = false;
+        clear();
+        auto fail = [&]() { std::cerr << ErrTag << " " << kk_last_error() << "\n"; };
+        const uint32_t *dim = cfg.volTex.GetDimension();
+        std::vector<T> rngs;
+        for (auto &r : cfg.emptyScalarRngs) {
+            rngs.push_back(r[0]);
+            rngs.push_back(r[1]);
+        }
+        const uint32_t nRng = static_cast<uint32_t>(cfg.emptyScalarRngs.size());
+        for (auto l : cfg.log2Dims)
+            if (!(l > 0 && l <= MaxLog2Dim)) {
+                std::cerr << ErrTag << " log2Dim > 0 && log2Dim <= MaxLog2Dim should be true.\n";
+                return;
+            }
+        const uint32_t B = 1u << cfg.log2Dims[0];
+        const size_t slots = static_cast<size_t>((dim[0] + B - 1) / B) * ((dim[1] + B - 1) / B) * ((dim[2] + B - 1) / B);
+        HIP::DeviceBuffer<uint32_t> d_valid(slots);
+        if (Fn<T>::classify(cfg.volTex.Get(), dim[0], dim[1], dim[2], cfg.log2Dims[0], rngs.data(), nRng,
+                            d_valid.data(), nullptr) != KK_OK)
+            return fail();
+        auto valid = d_valid.to_host();
+        kk_vdb_plan plan;
+        if (kk_vdb_plan_build(dim[0], dim[1], dim[2], cfg.log2Dims.data(), cfg.apronWid, cfg.useDepthBox,
+                              valid.data(), &plan) != KK_OK)
+            return fail();
+        std::vector<Node> nodes(plan.node_num);
+        std::vector<RelativeIndexTy> children(plan.child_num), amap(plan.atlas_map_num);
+        if (kk_vdb_wire(&plan, valid.data(), nodes.data(), children.data(), amap.data()) != KK_OK)
+            return fail();
+        if (!d_nodePools.assign(nodes) || !d_childPools.assign(children) ||
+            !d_atlasBrickToNodeIndices.assign(amap) || !d_atlas.resize(plan.atlas_voxels * sizeof(T)))
+            return fail();
+        if (Fn<T>::fill(cfg.volTex.Get(), dim[0], dim[1], dim[2], &plan, d_nodePools.data(), rngs.data(), nRng,
+                        reinterpret_cast<T *>(d_atlas.data()), nullptr) != KK_OK)
+            return fail();
+        deviceDat.node_pools = d_nodePools.data();
+        deviceDat.child_pools = d_childPools.data();
+        deviceDat.atlas_brick_to_node_indices = d_atlasBrickToNodeIndices.data();
+        deviceDat.atlas = d_atlas.data();
+        deviceDat.leaf_num = plan.leaf_num;
+        deviceDat.voxel_bytes = sizeof(T);
+        deviceDat.vdb_param = plan.param;
+        if (!d_deviceDat.size())
+            d_deviceDat.resize(1);
+        kk_memcpy_h2d(d_deviceDat.data(), &deviceDat, sizeof(deviceDat), nullptr);
+        kk_stream_synchronize(nullptr);
+        std::cout << "Build VDB with\n\tNode pools of size " << d_nodePools.size() << "x" << sizeof(Node)
+                  << "\n\tChild pools of size " << d_childPools.size() << "x4\n\tMaps from atlas brick to node index of size "
+                  << d_atlasBrickToNodeIndices.size() << "x4\n\tAtlas of " << plan.leaf_num << " bricks of "
+                  << plan.param.vox_per_atlas_brick << "^3x" << sizeof(T) << "\n";
+        isComplete = true;
+    }
+
+    bool IsComplete() const { return isComplete; }
+    const DeviceData *GetDeivceDataDevicePtr() const { return d_deviceDat.data(); }
+    const DeviceData &GetDeviceData() const { return deviceDat; }
+    size_t GetNodePoolsSize() const { return d_nodePools.size(); }
+    size_t GetChildPoolsSize() const { return d_childPools.size(); }
+    size_t GetAtlasBrickToNodeIndicesSize() const { return d_atlasBrickToNodeIndices.size(); }
+
+  private:
+    void clear() {
+        d_nodePools.clear();
+        d_childPools.clear();
+        d_atlasBrickToNodeIndices.clear();
+        d_atlas.clear();
+    }
+};
+
+template <> struct DepthBoxVDB::Fn<uint8_t> {
+    static constexpr auto classify = kk_vdb_classify_u8;
+    static constexpr auto fill = kk_vdb_fill_atlas_u8;
+    static constexpr auto render = kk_dvr_render_u8;
+};
+template <> struct DepthBoxVDB::Fn<uint16_t> {
+    static constexpr auto classify = kk_vdb_classify_u16;
+    static constexpr auto fill = kk_vdb_fill_atlas_u16;
+    static constexpr auto render = kk_dvr_render_u16;
+};
+
+} // namespace RayCaster
+} // namespace kouek
+
+#endif // KOUEK_RAY_CASTER_DPBX_VDB_H

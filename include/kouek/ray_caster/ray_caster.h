@@ -1,0 +1,76 @@
+// kouek::RayCaster::RayCaster with the reference's public interface for the Depth-Box VDB path
+// (reference include/ray_caster/ray_caster.h:16-89, src/ray_caster/ray_caster.cu,
+// src/ray_caster/ray_caster_dpbx_vdb.cu:439-532). Surfaces and textures become HIP::FrameBuffer /
+// HIP::TransferFunctionTable. RenderRAWVolume and the debug targets are not implemented.
+#ifndef KOUEK_RAY_CASTER_RAY_CASTER_H
+#define KOUEK_RAY_CASTER_RAY_CASTER_H
+
+#include <memory>
+#include <string_view>
+
+#include "dpbx_vdb.h"
+
+namespace kouek {
+namespace RayCaster {
+
+class RayCaster : Noncopyable {
+  private:
+    kk_dvr_params rndrParam{};
+    kk_dvr_frame rndrParamPerFrame{};
+    std::shared_ptr<HIP::TransferFunctionTable> tfTex;
+    std::shared_ptr<DepthBoxVDB> vdb;
+    static constexpr std::string_view ErrTag = "[RayCaster Error]";
+
+  public:
+    RayCaster() {
+        rndrParam.max_alpha = .9f;
+        rndrParam.sampling_rate = 3.f;
+    }
+    void SetDepthBoxVDB(std::shared_ptr<DepthBoxVDB> vdb) { this->vdb = vdb; }
+    void SetMaximumAlpha(float maxAlpha) { rndrParam.max_alpha = maxAlpha; }
+    void SetSamplingRate(float samplingRate) { rndrParam.sampling_rate = samplingRate; }
+    void SetTransferFunctionTexture(std::shared_ptr<HIP::TransferFunctionTable> tfTex) { this->tfTex = tfTex; }
+    void SetWorldToScene(const mat4 &w2s) { std::memcpy(rndrParam.w2s, &w2s[0][0], 64); }
+    void SetCameraToWorld(const vec3 &eyePos2w, const mat3 &eyeRot2w) {
+        std::memcpy(rndrParamPerFrame.eye_pos, &eyePos2w[0], 12);
+        std::memcpy(rndrParamPerFrame.eye_rot, &eyeRot2w[0][0], 36);
+    }
+    void SetProjection(const mat4 &proj) {
+        auto invProj = Math::InverseProjective(proj);
+        std::memcpy(rndrParam.inv_proj, &invProj[0][0], 64);
+    }
+    struct InputShadingParameter {
+        float ka, kd, ks, shiness;
+        vec3 lightPosInVolumeSpace;
+        vec3 lightCol;
+    };
+    void SetShading(const InputShadingParameter &in) {
+        rndrParam.use_shading = 1;
+        rndrParam.ka = in.ka, rndrParam.kd = in.kd, rndrParam.ks = in.ks, rndrParam.shiness = in.shiness;
+        std::memcpy(rndrParam.light_pos, &in.lightPosInVolumeSpace[0], 12);
+        std::memcpy(rndrParam.light_col, &in.lightCol[0], 12);
+    }
+    void UnsetShading() { rndrParam.use_shading = 0; }
+
+    enum class DPBXVDBRenderTarget { Scene, AABBs, Depths, PositionsAfterDepthSkip };
+    template <typename T>
+    void RenderDepthBoxVDB(HIP::FrameBuffer &rndrTo, const ivec2 &rndrSz,
+                           DPBXVDBRenderTarget rndrTarget = DPBXVDBRenderTarget::Scene) {
+        if (!vdb || !tfTex || !vdb->IsComplete()) {
+            std::cerr << ErrTag << " at " << __FILE__ << ":" << __LINE__ << ". vdb or tfTex are not set.\n";
+            return;
+        }
+        if (rndrTarget != DPBXVDBRenderTarget::Scene) {
+            std::cerr << ErrTag << " only DPBXVDBRenderTarget::Scene is implemented.\n";
+            return;
+        }
+        auto fn = sizeof(T) == 1 ? kk_dvr_render_u8 : kk_dvr_render_u16;
+        KOUEK_HIP_CHECK(ErrTag.data(), fn(&vdb->GetDeviceData(), tfTex->Get(), &rndrParam, &rndrParamPerFrame,
+                                          rndrTo.Get(), rndrSz.x, rndrSz.y, 0, rndrSz.y, nullptr, nullptr));
+    }
+};
+
+} // namespace RayCaster
+} // namespace kouek
+
+#endif // KOUEK_RAY_CASTER_RAY_CASTER_H

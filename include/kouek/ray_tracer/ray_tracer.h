@@ -1,0 +1,179 @@
+// kouek::RayTracer::RayTracer with the reference's public interface (reference
+// include/ray_tracer/ray_tracer.h:23-136, src/ray_tracer/ray_tracer.cu, ray_tracer_render.cu:433-647).
+// Changes forced by the platform: Render takes a HIP::FrameBuffer instead of a cudaSurfaceObject_t, and
+// only RenderTarget::Scene is implemented (the other targets are debug views).
+#ifndef KOUEK_RAY_TRACER_RAY_TRACER_H
+#define KOUEK_RAY_TRACER_RAY_TRACER_H
+
+#include <memory>
+#include <string_view>
+#include <vector>
+
+#include "lbvh.h"
+#include "material.h"
+
+namespace kouek {
+namespace RayTracer {
+
+class RayTracer : Noncopyable {
+  public:
+    using IndexTy = uint32_t;
+    static constexpr float Eps = .001f;
+
+    struct alignas(16) Triangle {
+        uvec3 normIdx;
+        uvec3 texCoordIdx;
+        IndexTy grpIdx;
+    };
+    static_assert(sizeof(Triangle) == sizeof(kk_pt_triangle), "layout must match the C ABI");
+
+    enum class RenderTarget { Scene, AABBs, Triangles, Lights, Positions, Normals, TextureCoords, None };
+
+  private:
+    float prevMaxSamplePerPixel = 1024.f;
+    float maxSamplePerPixel = 1024.f;
+    float currAccuSamplePerPixel = 0.f;
+    const HIP::FrameBuffer *prevRndrTo = nullptr;
+    ivec2 prevRndrSz{0, 0};
+    RenderTarget prevRndrTarget = RenderTarget::None;
+
+    kk_pt_scene scene{};
+    kk_pt_frame frame{};
+    bool modified = true;
+    std::shared_ptr<LBVH> lbvh;
+
+    HIP::DeviceBuffer<Triangle> d_triangles;
+    HIP::DeviceBuffer<uvec3> d_triToPositionIndices;
+    HIP::DeviceBuffer<vec3> d_positions;
+    HIP::DeviceBuffer<vec3> d_normals;
+    HIP::DeviceBuffer<vec2> d_texCoords;
+    HIP::DeviceBuffer<Light> d_lights;
+    HIP::DeviceBuffer<Material> d_materials;
+    HIP::DeviceBuffer<vec3> d_accuRndrTo;
+
+    static constexpr std::string_view ErrTag = "[RayTracer Error]";
+    static constexpr uint32_t Seed = 1234; // curand_init(1234, pixel, 0) in the reference
+
+    template <typename T> void setIfChanged(T &dst, const T &src) {
+        if (std::memcmp(&dst, &src, sizeof(T)) != 0) {
+            dst = src;
+            modified = true;
+        }
+    }
+    void setFloats(float *dst, const float *src, int n) {
+        if (std::memcmp(dst, src, sizeof(float) * n) != 0) {
+            std::memcpy(dst, src, sizeof(float) * n);
+            modified = true;
+        }
+    }
+
+  public:
+    RayTracer() { scene.max_path_depth = 4; }
+
+    struct InputMesh {
+        const std::vector<vec3> &positions;
+        const std::vector<vec3> &normals;
+        const std::vector<vec2> &texCoords;
+        const std::vector<IndexTy> &groupStartFaceIndices;
+        const std::vector<uvec3> &facePositionIndices;
+        const std::vector<uvec3> &faceNormalIndices;
+        const std::vector<uvec3> &faceTexCoordIndices;
+        const std::vector<Light> &lights;
+        const std::vector<Material> &materials;
+    };
+
+    void SetMesh(const InputMesh &in) {
+        std::vector<Triangle> tris(in.facePositionIndices.size());
+        for (size_t fi = 0; fi < tris.size(); ++fi) {
+            tris[fi].normIdx = in.faceNormalIndices[fi];
+            tris[fi].texCoordIdx = in.faceTexCoordIndices[fi];
+            // group of a face: the last group that starts at or before it (ray_tracer.cu:43-57)
+            IndexTy gi;
+            for (gi = 1; gi < in.groupStartFaceIndices.size(); ++gi)
+                if (in.groupStartFaceIndices[gi] > fi)
+                    break;
+            tris[fi].grpIdx = gi - 1;
+        }
+        d_triangles.assign(tris);
+        d_triToPositionIndices.assign(in.facePositionIndices);
+        d_positions.assign(in.positions);
+        d_normals.assign(in.normals);
+        d_texCoords.assign(in.texCoords);
+        d_lights.assign(in.lights);
+        d_materials.assign(in.materials);
+        scene.light_num = static_cast<IndexTy>(in.lights.size());
+        scene.triangles = reinterpret_cast<const kk_pt_triangle *>(d_triangles.data());
+        scene.tri_to_position_indices = reinterpret_cast<const uint32_t *>(d_triToPositionIndices.data());
+        scene.positions = reinterpret_cast<const float *>(d_positions.data());
+        scene.normals = reinterpret_cast<const float *>(d_normals.data());
+        scene.tex_coords = reinterpret_cast<const float *>(d_texCoords.data());
+        scene.lights = reinterpret_cast<const kk_light *>(d_lights.data());
+        scene.materials = reinterpret_cast<const kk_material *>(d_materials.data());
+        float tot = 0.f;
+        for (auto &lht : in.lights)
+            tot += lht.area;
+        scene.light_tot_area = tot;
+        modified = true;
+    }
+    void SetLBVH(std::shared_ptr<LBVH> lbvh) { this->lbvh = lbvh; }
+    void SetWorldToScene(const mat4 &w2s) { setFloats(scene.w2s, &w2s[0][0], 16); }
+    void SetCameraToWorld(const vec3 &eyePos2w, const mat3 &eyeRot2w) {
+        setFloats(frame.eye_pos, &eyePos2w[0], 3);
+        setFloats(frame.eye_rot, &eyeRot2w[0][0], 9);
+    }
+    void SetProjection(const mat4 &proj) {
+        auto invProj = Math::InverseProjective(proj);
+        setFloats(scene.inv_proj, &invProj[0][0], 16);
+    }
+    void SetDisplayTreeHeight(uint8_t h) { setIfChanged(scene.display_tree_height, h); }
+    void SetMaxPathDepth(uint8_t d) { setIfChanged(scene.max_path_depth, d); }
+    void SetMaxSamplePerPixel(const float &v) { maxSamplePerPixel = v; }
+    const float GetMaxSamplePerPixel() const { return maxSamplePerPixel; }
+    const float GetCurrentAccumulatedSamplePerPixel() const { return currAccuSamplePerPixel; }
+
+    // One call adds one sample per pixel; accumulation restarts when a parameter, the size, the target
+    // or the framebuffer changed, and the call is a no-op once the sample budget is used up
+    // (ray_tracer_render.cu:561-577, 640-641).
+    void Render(HIP::FrameBuffer &rndrTo, const ivec2 &rndrSz, RenderTarget rndrTarget = RenderTarget::Scene) {
+        if (!lbvh || !lbvh->IsComplete()) {
+            std::cerr << ErrTag << " at " << __FILE__ << ":" << __LINE__ << ". lbvh is not set.\n";
+            return;
+        }
+        if (rndrTarget != RenderTarget::Scene) {
+            std::cerr << ErrTag << " only RenderTarget::Scene is implemented.\n";
+            return;
+        }
+        bool needRedraw = modified;
+        modified = false;
+        auto flatRes = static_cast<size_t>(rndrSz.x) * rndrSz.y;
+        if (prevRndrSz != rndrSz || d_accuRndrTo.size() != flatRes)
+            d_accuRndrTo.resize(flatRes);
+        needRedraw |= prevMaxSamplePerPixel != maxSamplePerPixel || prevRndrTo != &rndrTo ||
+                      prevRndrSz != rndrSz || prevRndrTarget != rndrTarget;
+        if (needRedraw) {
+            currAccuSamplePerPixel = 1.f;
+            d_accuRndrTo.zero();
+        }
+        prevRndrTo = &rndrTo;
+        prevRndrSz = rndrSz;
+        prevRndrTarget = rndrTarget;
+        if (currAccuSamplePerPixel > maxSamplePerPixel)
+            return;
+        if (!KOUEK_HIP_CHECK(ErrTag.data(),
+                             kk_pt_render_sample(reinterpret_cast<const kk_lbvh_device_data *>(
+                                                     lbvh->GetDeivceDataDevicePtr()),
+                                                 &scene, &frame, reinterpret_cast<float *>(d_accuRndrTo.data()),
+                                                 rndrTo.Get(), rndrSz.x, rndrSz.y, 0, rndrSz.y,
+                                                 currAccuSamplePerPixel, Seed, nullptr)))
+            return;
+        prevMaxSamplePerPixel = maxSamplePerPixel;
+        currAccuSamplePerPixel += 1.f;
+    }
+
+    std::vector<vec3> ReadAccumulation() const { return d_accuRndrTo.to_host(); }
+};
+
+} // namespace RayTracer
+} // namespace kouek
+
+#endif // KOUEK_RAY_TRACER_RAY_TRACER_H

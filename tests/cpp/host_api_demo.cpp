@@ -1,0 +1,122 @@
+// Exercises the C++ host classes the way the reference's two applications drive theirs
+// (app/rt_lbvh.cpp:163-296, app/dvr_dpbx_vdb.cpp:271-381), headless, and dumps the results as raw
+// binary files for tests/test_gpu_cpp_host.py to compare with the Python path and the CPU checker.
+//   host_api_demo <in_dir> <out_dir>
+// in_dir holds little-endian raw arrays written by the test (positions.f32, tri.u32, ...).
+#include <kouek/ray_caster/ray_caster.h>
+#include <kouek/ray_tracer/ray_tracer.h>
+
+#include <cstdio>
+#include <fstream>
+#include <string>
+
+using namespace kouek;
+
+template <typename T> static std::vector<T> load(const std::string &path) {
+    std::ifstream in(path, std::ios::binary | std::ios::ate);
+    if (!in)
+        return {};
+    size_t bytes = static_cast<size_t>(in.tellg());
+    std::vector<T> v(bytes / sizeof(T));
+    in.seekg(0);
+    in.read(reinterpret_cast<char *>(v.data()), bytes);
+    return v;
+}
+template <typename T> static void save(const std::string &path, const std::vector<T> &v) {
+    std::ofstream out(path, std::ios::binary);
+    out.write(reinterpret_cast<const char *>(v.data()), v.size() * sizeof(T));
+}
+
+int main(int argc, char **argv) {
+    if (argc < 3)
+        return 2;
+    const std::string in = argv[1], out = argv[2];
+    if (kk_set_device(0) != KK_OK) {
+        std::fprintf(stderr, "%s\n", kk_last_error());
+        return 1;
+    }
+    // ---------------- path 1: LBVH + path tracer ----------------
+    auto positions = load<vec3>(in + "/positions.f32");
+    auto normals = load<vec3>(in + "/normals.f32");
+    auto texCoords = load<vec2>(in + "/tex_coords.f32");
+    auto fpi = load<uvec3>(in + "/fpi.u32");
+    auto fni = load<uvec3>(in + "/fni.u32");
+    auto fti = load<uvec3>(in + "/fti.u32");
+    auto groups = load<uint32_t>(in + "/groups.u32");
+    auto lights = load<RayTracer::Light>(in + "/lights.bin");
+    auto materials = load<RayTracer::Material>(in + "/materials.bin");
+    auto cam = load<float>(in + "/camera.f32"); // proj 16, eyePos 3, eyeRot 9, W, H, spp
+    auto lbvh = std::make_shared<RayTracer::LBVH>();
+    lbvh->BuildFrom({positions, fpi}, out + "/lbvh.log");
+    if (!lbvh->IsComplete())
+        return 1;
+    {
+        auto dd = lbvh->GetDeviceData();
+        std::vector<uint32_t> hdr = {dd.faceNum, dd.compactedFaceNum};
+        save(out + "/lbvh_hdr.u32", hdr);
+        std::vector<RayTracer::LBVH::InternalNode> nodes(dd.compactedFaceNum - 1);
+        kk_memcpy_d2h(nodes.data(), dd.internalNodes, nodes.size() * 32, nullptr);
+        save(out + "/lbvh_nodes.bin", nodes);
+    }
+    RayTracer::RayTracer tracer;
+    tracer.SetWorldToScene(mat4::identity());
+    tracer.SetMesh({positions, normals, texCoords, groups, fpi, fni, fti, lights, materials});
+    tracer.SetLBVH(lbvh);
+    tracer.SetMaxPathDepth(4);
+    mat4 proj;
+    std::memcpy(static_cast<void *>(&proj), cam.data(), 64);
+    vec3 eye(cam[16], cam[17], cam[18]);
+    mat3 rot;
+    std::memcpy(static_cast<void *>(&rot), cam.data() + 19, 36);
+    ivec2 sz{static_cast<int>(cam[28]), static_cast<int>(cam[29])};
+    tracer.SetProjection(proj);
+    tracer.SetCameraToWorld(eye, rot);
+    HIP::FrameBuffer fb(sz);
+    for (int s = 0; s < static_cast<int>(cam[30]); ++s)
+        tracer.Render(fb, sz);
+    save(out + "/pt_accum.f32", tracer.ReadAccumulation());
+    std::vector<HIP::uchar4> img;
+    fb.ReadBack(img);
+    save(out + "/pt_rgba.u8", img);
+    std::vector<float> spp = {tracer.GetCurrentAccumulatedSamplePerPixel()};
+    save(out + "/pt_spp.f32", spp);
+
+    // ---------------- path 2: Depth-Box VDB + DVR ----------------
+    auto vol = load<uint8_t>(in + "/volume.u8");
+    auto vdim = load<uint32_t>(in + "/volume_dim.u32"); // dx dy dz, log2Dims[3]
+    auto rngs = load<std::array<uint8_t, 2>>(in + "/empty_rngs.u8");
+    auto tf = load<vec4>(in + "/tf.f32");
+    auto dcam = load<float>(in + "/dvr_camera.f32"); // w2s 16, proj 16, eyePos 3, eyeRot 9, W, H
+    HIP::Volume<uint8_t> volume(vol, vdim[0], vdim[1], vdim[2]);
+    auto vdb = std::make_shared<RayCaster::DepthBoxVDB>();
+    vdb->BuildFrom<uint8_t>({.apronWid = 1,
+                             .log2Dims = {uint8_t(vdim[3]), uint8_t(vdim[4]), uint8_t(vdim[5])},
+                             .useDepthBox = true,
+                             .volTex = volume,
+                             .emptyScalarRngs = rngs});
+    if (!vdb->IsComplete())
+        return 1;
+    RayCaster::RayCaster caster;
+    mat4 w2s, dproj;
+    std::memcpy(static_cast<void *>(&w2s), dcam.data(), 64);
+    std::memcpy(static_cast<void *>(&dproj), dcam.data() + 16, 64);
+    vec3 deye(dcam[32], dcam[33], dcam[34]);
+    mat3 drot;
+    std::memcpy(static_cast<void *>(&drot), dcam.data() + 35, 36);
+    ivec2 dsz{static_cast<int>(dcam[44]), static_cast<int>(dcam[45])};
+    caster.SetWorldToScene(w2s);
+    caster.SetDepthBoxVDB(vdb);
+    caster.SetTransferFunctionTexture(std::make_shared<HIP::TransferFunctionTable>(tf));
+    caster.SetProjection(dproj);
+    caster.SetCameraToWorld(deye, drot);
+    HIP::FrameBuffer dfb(dsz);
+    caster.RenderDepthBoxVDB<uint8_t>(dfb, dsz);
+    kk_stream_synchronize(nullptr);
+    dfb.ReadBack(img);
+    save(out + "/dvr_rgba.u8", img);
+    std::vector<uint64_t> sizes = {vdb->GetNodePoolsSize(), vdb->GetChildPoolsSize(),
+                                   vdb->GetAtlasBrickToNodeIndicesSize()};
+    save(out + "/vdb_sizes.u64", sizes);
+    std::printf("host_api_demo ok\n");
+    return 0;
+}
