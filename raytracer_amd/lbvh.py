@@ -38,6 +38,7 @@ class LBVH:
         self.d_positions = self.d_face_pos_idx = None
         self.d_faces = self.d_compacted = self.d_nodes = None
         self.d_device_data = self.d_workspace = None
+        self.d_accel = None
         self._host_dd = None
         self.ws_layout = None
         self.face_num = 0
@@ -119,6 +120,23 @@ class LBVH:
                                        self.d_nodes.data_ptr(), self.d_device_data.data_ptr(),
                                        self.d_workspace.data_ptr(), self.d_workspace.numel(), flags,
                                        _lib.current_stream_ptr()), "kk_lbvh_build")
+
+    def trace_accel(self, rebuild: bool = False):
+        """The trace-side layout of this tree (64-byte two-box node records + 48-byte triangle records),
+        built on first use on the current stream; `rebuild` repacks it over the same buffer."""
+        l = _lib.lib()
+        N, M = self.face_num, self.GetDeviceData()["compactedFaceNum"]
+        if getattr(self, "d_accel", None) is None or self._accel_sizes != (N, M):
+            self.d_accel = torch.empty(l.kk_trace_accel_bytes(N, M), dtype=torch.uint8, device=self.device)
+            self._accel_sizes = (N, M)
+            rebuild = True
+        if rebuild:
+            with torch.cuda.device(self.device):
+                _lib.check(l.kk_trace_accel_build(self.GetDeivceDataDevicePtr(), self.d_positions.data_ptr(),
+                                                  self.d_face_pos_idx.data_ptr(), N, M,
+                                                  self.d_accel.data_ptr(), self.d_accel.numel(),
+                                                  _lib.current_stream_ptr()), "kk_trace_accel_build")
+        return self.d_accel
 
     # -- read-back helpers (parity tests, logs) --------------------------------------------------------
     def stage(self, name: str, count: int, dtype) -> np.ndarray:
