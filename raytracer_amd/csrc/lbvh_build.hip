@@ -18,7 +18,8 @@
 namespace kk {
 namespace rsort {
 int sort_pairs(uint32_t *keysA, uint32_t *keysB, uint32_t *valsA, uint32_t *valsB, bool iota,
-               uint32_t n, void *ws, size_t wsBytes, hipStream_t stream, uint32_t **errorFlagOut);
+               uint32_t n, void *ws, size_t wsBytes, hipStream_t stream, uint32_t **errorFlagOut,
+               int passes);
 }
 extern "C" size_t kk_sort_workspace_bytes(uint32_t n);
 
@@ -609,7 +610,7 @@ extern "C" int kk_lbvh_build(const float *d_positions, uint32_t vert_num,
 
     // payload = face index; four passes leave keys in keys0 and faces in d_faces
     int rc = rsort::sort_pairs(keys0, keys1, d_faces, vals1, true, N, b + w.sortWs, w.sortWsBytes,
-                               stream, nullptr);
+                               stream, nullptr, 4);
     if (rc != KK_OK)
         return rc;
 

@@ -254,8 +254,11 @@ inline SortWs sort_ws(uint32_t n) {
 }
 
 // Enqueues the whole sort. errorFlagOut (optional) receives the device address of the error word.
+// `passes` (1..4) sorts on the low 8 * passes key bits only; after an odd number of passes the result
+// is in the B arrays.
 int sort_pairs(uint32_t *keysA, uint32_t *keysB, uint32_t *valsA, uint32_t *valsB, bool iota,
-               uint32_t n, void *ws, size_t wsBytes, hipStream_t stream, uint32_t **errorFlagOut) {
+               uint32_t n, void *ws, size_t wsBytes, hipStream_t stream, uint32_t **errorFlagOut,
+               int passes) {
     SortWs w = sort_ws(n);
     if (wsBytes < w.total) {
         set_error("sort workspace too small: %zu < %zu", wsBytes, w.total);
@@ -276,7 +279,7 @@ int sort_pairs(uint32_t *keysA, uint32_t *keysB, uint32_t *valsA, uint32_t *vals
     KK_LAUNCH_CHECK();
 
     uint32_t *kin = keysA, *kout = keysB, *vin = valsA, *vout = valsB;
-    for (int p = 0; p < PASSES; ++p) {
+    for (int p = 0; p < passes; ++p) {
         uint32_t *st = status + static_cast<size_t>(p) * w.tiles * RADIX;
         if (p == 0 && iota)
             onesweep_pass_kernel<true><<<w.tiles, THREADS, 0, stream>>>(
@@ -307,5 +310,5 @@ extern "C" int kk_sort_pairs_u32(uint32_t *d_keys_a, uint32_t *d_keys_b, uint32_
     KK_REQUIRE(n > 0 && n <= KK_LBVH_MAX_FACES, "n out of range");
     return kk::rsort::sort_pairs(d_keys_a, d_keys_b, d_vals_a, d_vals_b, vals_are_iota != 0, n,
                                  d_workspace, workspace_bytes, static_cast<hipStream_t>(stream),
-                                 nullptr);
+                                 nullptr, kk::rsort::PASSES);
 }

@@ -1,28 +1,48 @@
 // Trace-side layout of a built LBVH and the closest-hit kernel that walks it.
 //
-// The reference's tree (32-byte nodes holding their OWN box, children found through faces ->
-// triToPositionIndices -> positions, src/ray_tracer/lbvh.cu:317-321) costs a ray one scattered line
-// per child box and four dependent gathers per triangle. For tracing, the same binary tree is
-// repacked once after the build:
-//   * WideNode (64 B, one aligned half line): both children's ids and both children's boxes. For an
-//     internal child the box is that child's own box, bit for bit, so the slab test decides exactly
-//     what rayCastLBVH (src/ray_tracer/ray_tracer_render.cu:192-270) decides when it visits the
-//     child. For a leaf child (which the reference's layout gives no box) it is the box of the
-//     leaf's triangles grown by a small pad; it only ever lets the walk skip triangles the ray
-//     cannot reach.
-//   * TriRec (48 B): the three vertices and the face index of the triangle at sorted position k, so a
-//     triangle test is one contiguous fetch; the Moeller-Trumbore arithmetic is unchanged.
-// Rays are traced in Morton order of their origin (ties: direction octant), found with the same radix
-// sort the build uses; results are written back at the ray's own index, so callers see no reordering.
-// The closest hit is defined as in traverse.h: smallest t, ties to the smaller sorted position k.
+// What decides a hit in the reference. rayCastLBVH (src/ray_tracer/ray_tracer_render.cu:192-270) tests
+// a triangle when the ray passed the slab test (include/cg/ray.h:29-45) of every internal node above
+// the triangle's leaf. A node's box is the exact union of its children's boxes (min / max of floats,
+// src/ray_tracer/lbvh.cu:286-310), and b -> fl(fl(b - o) / d) is monotonic in b, so for a ray whose
+// direction components are all non-zero the per-axis intervals of an ancestor contain those of a
+// descendant and so do [tEnter, tExit]: passing the test of the leaf's PARENT node implies passing
+// the test of every node above it. Hence
+//     triangle k is a candidate of the reference  <=>  the ray passes the slab test of parent(leaf(k)),
+// and the closest hit is the candidate with the smallest Moeller-Trumbore t (ties: smallest sorted
+// position k, see traverse.h). How candidates are FOUND is free, as long as none is missed.
+//
+// So the binary tree is repacked once after the build, for finding candidates fast:
+//   * Node4 (128 B, one cache line) per binary node n: the boxes and ids of n's four grandchildren
+//     (a child that is a leaf takes one slot itself). Boxes are stored per axis (4 mins, 4 maxs) so a
+//     lane fetches "near" and "far" planes directly by the sign of its ray direction. Leaf slots hold
+//     the box of the leaf's triangles grown by a small pad.
+//   * TriRec (48 B) per sorted triangle position k: three vertices, face index, index of the leaf's
+//     parent node.
+// The walk uses a reciprocal-multiply slab test made conservative by a relative margin (it may visit
+// more than the reference, never less). A triangle whose Moeller-Trumbore test (same arithmetic as
+// 3rd/glm/gtx/intersect.inl:28-94) beats the best hit is accepted only after the slab test of its
+// leaf's parent box: decided by the fast test when that is outside its error margin, by the
+// reference's division form otherwise. Rays with a (near-)zero direction component, where plane
+// distances become inf / NaN and the containment argument does not hold, are handed to the exact
+// walker of traverse.hip through a list.
+// Rays are traced in Morton order of their origins (radix sort of (key, index)); outputs are written
+// at the ray's own index.
 #include "kk_host.h"
 #include "kk_math.h"
 #include "traverse.h"
+#include <stdlib.h>
 
 namespace kk {
 namespace rsort {
 int sort_pairs(uint32_t *keysA, uint32_t *keysB, uint32_t *valsA, uint32_t *valsB, bool iota,
-               uint32_t n, void *ws, size_t wsBytes, hipStream_t stream, uint32_t **errorFlagOut);
+               uint32_t n, void *ws, size_t wsBytes, hipStream_t stream, uint32_t **errorFlagOut,
+               int passes);
+}
+namespace trav {
+int launch_listed(const kk_lbvh_device_data *lbvh, const float *positions, const uint32_t *tri,
+                  const float *rays, float *tOut, float *baryOut, uint32_t *primOut,
+                  uint32_t *rayCounter, const uint32_t *list, const uint32_t *listCount,
+                  hipStream_t stream);
 }
 extern "C" size_t kk_sort_workspace_bytes(uint32_t n);
 
@@ -33,27 +53,29 @@ using trav::LEAF_MASK;
 
 constexpr int THREADS = 256;
 constexpr float LEAF_PAD = 1e-5f; // leaf boxes grow by this fraction of the scene's largest coordinate
+constexpr uint32_t EMPTY = 0xFFFFFFFFu;
 
-struct alignas(64) WideNode {
-    uint32_t child[2]; // internal: node index; leaf: LEAF | first sorted position k
-    uint32_t cnt[2];   // leaf: number of triangles (0 for an internal child or a repeated leaf)
-    float box[2][6];   // min xyz, max xyz of each child
+struct alignas(128) Node4 {
+    float plane[6][4]; // minx[4] maxx[4] miny[4] maxy[4] minz[4] maxz[4]
+    uint32_t child[4]; // binary node index | LEAF + first sorted position | EMPTY
+    uint32_t cnt[4];   // triangles of a leaf slot, 0 otherwise
 };
-static_assert(sizeof(WideNode) == 64, "one half cache line");
+static_assert(sizeof(Node4) == 128, "one cache line");
 
 struct alignas(16) TriRec {
     float v0[3];
     uint32_t fi;
     float v1[3];
-    uint32_t pad0;
+    uint32_t parent; // binary node whose child is this triangle's leaf
     float v2[3];
-    uint32_t pad1;
+    uint32_t pad;
 };
 static_assert(sizeof(TriRec) == 48, "three 16-byte loads");
 
 struct alignas(256) Header {
     float rootBox[6];
     uint32_t faceNum, nodeNum;
+    const kk_lbvh_node *nodes; // the build's own nodes (parent boxes for the acceptance test)
 };
 
 struct Layout {
@@ -64,7 +86,7 @@ inline Layout layout(uint32_t faceNum, uint32_t compactedNum) {
     Carver c;
     const uint32_t nodeNum = compactedNum > 1 ? compactedNum - 1 : 1;
     l.header = c.take(sizeof(Header));
-    l.nodes = c.take(sizeof(WideNode) * static_cast<size_t>(nodeNum));
+    l.nodes = c.take(sizeof(Node4) * static_cast<size_t>(nodeNum));
     l.tris = c.take(sizeof(TriRec) * static_cast<size_t>(faceNum));
     l.total = c.off;
     return l;
@@ -80,20 +102,59 @@ __global__ __launch_bounds__(THREADS) void pack_tris_kernel(
     const uint32_t i0 = tri[3ull * fi], i1 = tri[3ull * fi + 1], i2 = tri[3ull * fi + 2];
     const f3 a = trav::load_pos(positions, i0), b = trav::load_pos(positions, i1),
              c = trav::load_pos(positions, i2);
-    uint4 *o = reinterpret_cast<uint4 *>(recs + k);
-    o[0] = make_uint4(__float_as_uint(a.x), __float_as_uint(a.y), __float_as_uint(a.z), fi);
-    o[1] = make_uint4(__float_as_uint(b.x), __float_as_uint(b.y), __float_as_uint(b.z), 0u);
-    o[2] = make_uint4(__float_as_uint(c.x), __float_as_uint(c.y), __float_as_uint(c.z), 0u);
+    // .parent is written by make_node4_kernel
+    float *o = reinterpret_cast<float *>(recs + k);
+    o[0] = a.x, o[1] = a.y, o[2] = a.z;
+    reinterpret_cast<uint32_t *>(o)[3] = fi;
+    o[4] = b.x, o[5] = b.y, o[6] = b.z;
+    o[8] = c.x, o[9] = c.y, o[10] = c.z;
+    reinterpret_cast<uint32_t *>(o)[11] = 0u;
 }
 
-__global__ __launch_bounds__(THREADS) void make_wide_kernel(
-    const kk_lbvh_device_data *__restrict__ lbvh, const TriRec *__restrict__ recs,
-    WideNode *__restrict__ wide, Header *__restrict__ hdr, uint32_t nodeNum) {
-    const uint32_t i = blockIdx.x * THREADS + threadIdx.x;
-    if (i >= nodeNum)
+struct Slot {
+    AABB box;
+    uint32_t child, cnt;
+};
+
+__device__ __forceinline__ Slot empty_slot() {
+    Slot s;
+    s.box.minPos = F3(__builtin_inff());
+    s.box.maxPos = F3(-__builtin_inff());
+    s.child = EMPTY;
+    s.cnt = 0u;
+    return s;
+}
+
+__device__ __forceinline__ Slot leaf_slot(const kk_lbvh_device_data *__restrict__ lbvh,
+                                          TriRec *__restrict__ recs, uint32_t leaf, uint32_t parent,
+                                          float pad) {
+    const uint32_t l = leaf & LEAF_MASK;
+    const uint32_t k0 = lbvh->compacted_faces[l];
+    const uint32_t k1 = (l == lbvh->compacted_face_num - 1) ? lbvh->face_num
+                                                            : lbvh->compacted_faces[l + 1];
+    Slot s;
+    s.box = AABB::Initial();
+    for (uint32_t k = k0; k < k1; ++k) {
+        TriRec &r = recs[k];
+        s.box.Expand(F3(r.v0[0], r.v0[1], r.v0[2]));
+        s.box.Expand(F3(r.v1[0], r.v1[1], r.v1[2]));
+        s.box.Expand(F3(r.v2[0], r.v2[1], r.v2[2]));
+        r.parent = parent; // every writer of this word writes the same value
+    }
+    s.box.minPos = s.box.minPos - pad;
+    s.box.maxPos = s.box.maxPos + pad;
+    s.child = LEAF | k0;
+    s.cnt = k1 - k0;
+    return s;
+}
+
+__global__ __launch_bounds__(THREADS) void make_node4_kernel(
+    const kk_lbvh_device_data *__restrict__ lbvh, TriRec *__restrict__ recs,
+    Node4 *__restrict__ out, Header *__restrict__ hdr, uint32_t nodeNum) {
+    const uint32_t n = blockIdx.x * THREADS + threadIdx.x;
+    if (n >= nodeNum)
         return;
     const kk_lbvh_node *nodes = lbvh->internal_nodes;
-    const uint32_t faceNum = lbvh->face_num, leafNum = lbvh->compacted_face_num;
     const trav::NodeData root = trav::load_node(nodes, 0);
     float scale = 0.f;
     for (int a = 0; a < 3; ++a) {
@@ -102,57 +163,59 @@ __global__ __launch_bounds__(THREADS) void make_wide_kernel(
         scale = fmaxf(scale, root.box.maxPos[a] - root.box.minPos[a]);
     }
     const float pad = LEAF_PAD * scale;
-    if (i == 0) {
+    if (n == 0) {
         for (int a = 0; a < 3; ++a) {
             hdr->rootBox[a] = root.box.minPos[a];
             hdr->rootBox[3 + a] = root.box.maxPos[a];
         }
-        hdr->faceNum = faceNum;
+        hdr->faceNum = lbvh->face_num;
         hdr->nodeNum = nodeNum;
+        hdr->nodes = nodes;
     }
-    const trav::NodeData me = trav::load_node(nodes, i);
-    WideNode w;
+    const trav::NodeData me = trav::load_node(nodes, n);
     const uint32_t ch[2] = {me.lft, me.rht};
+    Slot slot[4];
     for (int s = 0; s < 2; ++s) {
         const uint32_t c = ch[s];
-        AABB box;
-        if (c & LEAF) {
-            const uint32_t l = c & LEAF_MASK;
-            const uint32_t k0 = lbvh->compacted_faces[l];
-            const uint32_t k1 = (l == leafNum - 1) ? faceNum : lbvh->compacted_faces[l + 1];
-            box = AABB::Initial();
-            for (uint32_t k = k0; k < k1; ++k) {
-                const TriRec &r = recs[k];
-                box.Expand(F3(r.v0[0], r.v0[1], r.v0[2]));
-                box.Expand(F3(r.v1[0], r.v1[1], r.v1[2]));
-                box.Expand(F3(r.v2[0], r.v2[1], r.v2[2]));
-            }
-            box.minPos = box.minPos - pad;
-            box.maxPos = box.maxPos + pad;
-            w.child[s] = LEAF | k0;
-            w.cnt[s] = (s == 1 && ch[0] == ch[1]) ? 0u : (k1 - k0); // single-leaf tree: test it once
+        if (s == 1 && ch[0] == ch[1] && (c & LEAF)) { // single-leaf tree: the leaf appears once
+            slot[2] = slot[3] = empty_slot();
+        } else if (c & LEAF) {
+            slot[2 * s] = leaf_slot(lbvh, recs, c, n, pad);
+            slot[2 * s + 1] = empty_slot();
         } else {
-            box = trav::load_node(nodes, c).box;
-            w.child[s] = c;
-            w.cnt[s] = 0u;
-        }
-        for (int a = 0; a < 3; ++a) {
-            w.box[s][a] = box.minPos[a];
-            w.box[s][3 + a] = box.maxPos[a];
+            const trav::NodeData g = trav::load_node(nodes, c);
+            const uint32_t gc[2] = {g.lft, g.rht};
+            for (int t = 0; t < 2; ++t) {
+                if (gc[t] & LEAF)
+                    slot[2 * s + t] = leaf_slot(lbvh, recs, gc[t], c, pad);
+                else {
+                    slot[2 * s + t].box = trav::load_node(nodes, gc[t]).box;
+                    slot[2 * s + t].child = gc[t];
+                    slot[2 * s + t].cnt = 0u;
+                }
+            }
         }
     }
-    uint4 *o = reinterpret_cast<uint4 *>(wide + i);
+    Node4 w;
+    for (int i = 0; i < 4; ++i) {
+        for (int a = 0; a < 3; ++a) {
+            w.plane[2 * a][i] = slot[i].box.minPos[a];
+            w.plane[2 * a + 1][i] = slot[i].box.maxPos[a];
+        }
+        w.child[i] = slot[i].child;
+        w.cnt[i] = slot[i].cnt;
+    }
+    uint4 *o = reinterpret_cast<uint4 *>(out + n);
     const uint4 *src = reinterpret_cast<const uint4 *>(&w);
-    o[0] = src[0];
-    o[1] = src[1];
-    o[2] = src[2];
-    o[3] = src[3];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        o[i] = src[i];
 }
 
 // ---- ray ordering ---------------------------------------------------------------------------------
 
-__device__ __forceinline__ uint32_t spread3(uint32_t v) { // 9 bits -> every third bit
-    v &= 0x1ffu;
+__device__ __forceinline__ uint32_t spread3(uint32_t v) { // 10 bits -> every third bit
+    v &= 0x3ffu;
     v = (v | (v << 16)) & 0x030000ffu;
     v = (v | (v << 8)) & 0x0300f00fu;
     v = (v | (v << 4)) & 0x030c30c3u;
@@ -160,7 +223,10 @@ __device__ __forceinline__ uint32_t spread3(uint32_t v) { // 9 bits -> every thi
     return v;
 }
 
-// key = 27-bit Morton code of the origin inside the root box (9 bits per axis, clamped) << 3 | octant
+// key = Morton code of the origin inside the root box, KEY_BITS bits per axis (clamped); sorted with
+// KEY_PASSES 8-bit passes
+constexpr int KEY_BITS = 8;
+constexpr int KEY_PASSES = (3 * KEY_BITS + 7) / 8;
 __global__ __launch_bounds__(THREADS) void ray_keys_kernel(const Header *__restrict__ hdr,
                                                            const float *__restrict__ rays,
                                                            uint32_t rayNum,
@@ -174,59 +240,58 @@ __global__ __launch_bounds__(THREADS) void ray_keys_kernel(const Header *__restr
         const float lo = hdr->rootBox[a], hi = hdr->rootBox[3 + a];
         const float ext = hi - lo;
         float u = ext > 0.f ? (p[a] - lo) / ext : 0.f;
-        u = fminf(fmaxf(u * 512.f, 0.f), 511.f); // NaN -> 0
+        u = fminf(fmaxf(u * float(1 << KEY_BITS), 0.f), float((1 << KEY_BITS) - 1)); // NaN -> 0
         code |= spread3(static_cast<uint32_t>(u)) << (2 - a);
     }
-    const uint32_t oct = (p[3] < 0.f ? 4u : 0u) | (p[4] < 0.f ? 2u : 0u) | (p[5] < 0.f ? 1u : 0u);
-    keys[r] = (code << 3) | oct;
+    keys[r] = code;
 }
 
 // ---- traversal ------------------------------------------------------------------------------------
 
-constexpr int STACK_DEPTH = 32; // internal-node depth <= 30: every level fixes one more Morton bit
-constexpr int LDS_DEPTH = 12;   // entries kept in LDS; deeper ones (rare) live in the workspace
-constexpr int REFILL_BELOW = 40;
-constexpr int PARK_MIN = 16; // run the triangle code once this many lanes wait for it ...
-constexpr int STEP_MIN = 24; // ... or fewer than this many lanes can still step
-constexpr uint32_t MAX_GRID = 1280; // 18 KB of LDS and < 96 VGPRs: five workgroups per CU
+constexpr int STACK_DEPTH = 48; // <= 3 pushes per visited record, <= 15 records deep (tree depth <= 30)
+constexpr int LDS_DEPTH = 20;   // entries kept in LDS; deeper ones (rare) live in the workspace
+constexpr int REFILL_BELOW_D = 40;
+constexpr int PARK_MIN_D = 16; // run the triangle code once this many lanes wait for it ...
+constexpr int STEP_MIN_D = 24; // ... or fewer than this many lanes can still step
+constexpr uint32_t MAX_GRID = 1280; // 30 KB of LDS and < 96 VGPRs: five workgroups per CU
+// A product (b - o) * (1 / d) is within 3 * 2^-24 of the reference's fl((b - o) / d) (one rounding
+// each in 1 / d, the product, and the quotient it stands for); min / max keep the bound.
+constexpr float SLAB_REL = 1e-6f, SLAB_ABS = 1e-30f;
 
+__device__ __forceinline__ float4 ld4(const char *p) { return *reinterpret_cast<const float4 *>(p); }
 
-__device__ __forceinline__ void load_wide(const WideNode *__restrict__ wide, uint32_t i,
-                                          uint32_t (&child)[2], uint32_t (&cnt)[2], AABB (&box)[2]) {
-    const uint4 *p = reinterpret_cast<const uint4 *>(wide + i);
-    const uint4 a = p[0], b = p[1], c = p[2], d = p[3];
-    child[0] = a.x;
-    child[1] = a.y;
-    cnt[0] = a.z;
-    cnt[1] = a.w;
-    box[0].minPos = {__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z)};
-    box[0].maxPos = {__uint_as_float(b.w), __uint_as_float(c.x), __uint_as_float(c.y)};
-    box[1].minPos = {__uint_as_float(c.z), __uint_as_float(c.w), __uint_as_float(d.x)};
-    box[1].maxPos = {__uint_as_float(d.y), __uint_as_float(d.z), __uint_as_float(d.w)};
-}
-
-// Slab test with the ray's reciprocal direction. Each plane distance differs from the reference's
-// (b - o) / d by at most 3 * 2^-24 relative (one rounding in 1/d, one in the product, one in the
-// quotient it stands for), and min / max keep that bound, so the sign of enter - exit is only in
-// doubt inside `SLAB_DOUBT`; there the caller repeats the test with the divisions.
-constexpr float SLAB_DOUBT = 5e-7f;
-struct FastRay {
-    f3 pos, inv;
+struct RayState {
+    f3 pos, dir, inv;
 };
-__device__ __forceinline__ void slab_fast(const FastRay &r, const AABB &b, float &en, float &ex,
-                                          bool &doubt) {
-    const float h0 = (b.minPos.x - r.pos.x) * r.inv.x, h1 = (b.maxPos.x - r.pos.x) * r.inv.x;
-    const float h2 = (b.minPos.y - r.pos.y) * r.inv.y, h3 = (b.maxPos.y - r.pos.y) * r.inv.y;
-    const float h4 = (b.minPos.z - r.pos.z) * r.inv.z, h5 = (b.maxPos.z - r.pos.z) * r.inv.z;
-    en = fmaxf(fmaxf(fminf(h0, h1), fminf(h2, h3)), fminf(h4, h5));
-    ex = fminf(fminf(fmaxf(h0, h1), fmaxf(h2, h3)), fmaxf(h4, h5));
+
+// Does `r` pass the slab test of the build's node `parent`, as the reference computes it?
+__device__ __forceinline__ bool passes_parent(const kk_lbvh_node *__restrict__ nodes, uint32_t parent,
+                                              const RayState &r) {
+    const trav::NodeData nd = trav::load_node(nodes, parent);
+    const float h0 = (nd.box.minPos.x - r.pos.x) * r.inv.x, h1 = (nd.box.maxPos.x - r.pos.x) * r.inv.x;
+    const float h2 = (nd.box.minPos.y - r.pos.y) * r.inv.y, h3 = (nd.box.maxPos.y - r.pos.y) * r.inv.y;
+    const float h4 = (nd.box.minPos.z - r.pos.z) * r.inv.z, h5 = (nd.box.maxPos.z - r.pos.z) * r.inv.z;
+    float en = fmaxf(fmaxf(fminf(h0, h1), fminf(h2, h3)), fminf(h4, h5));
+    const float ex = fminf(fminf(fmaxf(h0, h1), fmaxf(h2, h3)), fmaxf(h4, h5));
     en = fmaxf(en, 0.f);
-    doubt = fabsf(en - ex) <= SLAB_DOUBT * fmaxf(en, fabsf(ex)) + 1e-30f;
+    const float m = SLAB_REL * fmaxf(en, fabsf(ex)) + SLAB_ABS;
+    if (en <= ex - m)
+        return true;
+    if (en > ex + m)
+        return false;
+    Ray ray{r.pos, r.dir};
+    float tEnter, tExit;
+    HitAABB(ray, nd.box, tEnter, tExit);
+    return !(tEnter > tExit);
 }
 
+// Triangles [k0, k0 + n) against the ray. A better hit is taken at once; whether its leaf's parent box
+// passes the reference's slab test is checked once, for the final hit, when the ray retires.
 template <bool COUNT>
-__device__ __forceinline__ void test_run(const TriRec *__restrict__ recs, const Ray &ray, uint32_t k0,
-                                         uint32_t n, trav::Hit &best, uint32_t &triTests) {
+__device__ __forceinline__ void test_run(const TriRec *__restrict__ recs, const RayState &r,
+                                         uint32_t k0, uint32_t n, trav::Hit &best,
+                                         uint32_t &triTests) {
+    const Ray ray{r.pos, r.dir};
     for (uint32_t k = k0; k < k0 + n; ++k) {
         const uint4 *p = reinterpret_cast<const uint4 *>(recs + k);
         const uint4 a = p[0], b = p[1], c = p[2];
@@ -247,19 +312,33 @@ __device__ __forceinline__ void test_run(const TriRec *__restrict__ recs, const 
     }
 }
 
-// Persistent wave64 workgroups pull rays (in sorted order) from a global counter; idle lanes are
-// refilled with one ballot + one atomic per wave. A lane that reaches leaf triangles parks them
-// (`pendCnt`) and waits; the wave runs the triangle code only when enough lanes are parked or too few
-// can still step, so the two code paths are not both paid for on every iteration.
+// compare-exchange of (key, id) pairs, ascending by key
+__device__ __forceinline__ void cswap(float &ka, uint32_t &ia, float &kb, uint32_t &ib) {
+    const bool sw = kb < ka;
+    const float k0 = sw ? kb : ka, k1 = sw ? ka : kb;
+    const uint32_t i0 = sw ? ib : ia, i1 = sw ? ia : ib;
+    ka = k0, kb = k1, ia = i0, ib = i1;
+}
+
+// Persistent wave64 workgroups pull rays (in sorted order) from a global counter. Per iteration every
+// lane is at the same place in the code: (A) lanes that need a node pop one stack entry, (B) lanes
+// with a node visit it, (C) when enough lanes have parked leaf triangles (or too few can still step)
+// the parked lanes test them. A finished ray waits until the wave refills: then all finished lanes
+// check their final hit against its leaf's parent box, write their result (or hand the ray to the
+// exact walker if the check fails) and take new rays with one ballot + one atomic per wave.
+//
+// Taking a better triangle hit without checking its parent box first is safe: the limit that prunes
+// the walk is never below the final t, so nothing closer is skipped; if the final hit itself fails
+// the check, the ray is redone exactly.
 template <bool COUNT>
 __global__ __launch_bounds__(THREADS) void closest_hit_accel_kernel(
-    const Header *__restrict__ hdr, const WideNode *__restrict__ wide,
-    const TriRec *__restrict__ recs, const float *__restrict__ rays,
-    const uint32_t *__restrict__ order, uint32_t rayNum, float *__restrict__ tOut,
-    float *__restrict__ baryOut, uint32_t *__restrict__ primOut, uint32_t *rayCounter,
-    uint2 *__restrict__ spill, unsigned long long *counters) {
-    // far children waiting to be visited: node index + entry distance cut to its upper 16 bits (a
-    // lower bound of a non-negative float, so the test on pop can only keep more)
+    const Header *__restrict__ hdr, const Node4 *__restrict__ node4, const TriRec *__restrict__ recs,
+    const float *__restrict__ rays, const uint32_t *__restrict__ order, uint32_t rayNum,
+    float *__restrict__ tOut, float *__restrict__ baryOut, uint32_t *__restrict__ primOut,
+    uint32_t *rayCounter, uint32_t *__restrict__ exactList, uint32_t *exactCount,
+    uint2 *__restrict__ spill, unsigned long long *counters, int REFILL_BELOW, int PARK_MIN, int STEP_MIN) {
+    // nodes waiting to be visited: node index + entry distance cut to its upper 16 bits (a lower
+    // bound of a non-negative float, so the test on pop can only keep more)
     __shared__ uint32_t s_node[LDS_DEPTH * THREADS];
     __shared__ unsigned short s_enter[LDS_DEPTH * THREADS];
     const int tid = threadIdx.x;
@@ -269,26 +348,57 @@ __global__ __launch_bounds__(THREADS) void closest_hit_accel_kernel(
     const unsigned long long lanesBelow = (1ull << lane) - 1ull;
     const size_t spillStride = static_cast<size_t>(gridDim.x) * THREADS;
     uint2 *mySpill = spill + static_cast<size_t>(blockIdx.x) * THREADS + tid;
+    const kk_lbvh_node *nodes = hdr->nodes;
+    const char *node4Bytes = reinterpret_cast<const char *>(node4);
 
     AABB rootBox;
     rootBox.minPos = {hdr->rootBox[0], hdr->rootBox[1], hdr->rootBox[2]};
     rootBox.maxPos = {hdr->rootBox[3], hdr->rootBox[4], hdr->rootBox[5]};
 
-    bool active = false, poolEmpty = false;
+    bool active = false;   // walking, or holding parked triangles
+    bool finished = false; // walk over, result not yet written
+    bool poolEmpty = false;
     uint32_t rayIdx = 0;
-    Ray ray;
-    FastRay fray;
-    bool exactOnly = false; // a direction component near zero: plane distances can be inf / NaN
-    uint32_t cur = 0;       // node to visit next
+    RayState ray;
+    uint32_t offX = 0, offY = 32, offZ = 64; // byte offsets of the near planes inside a Node4
+    uint32_t cur = 0;                        // node to visit next
+    bool needNode = false;                   // cur is used up: take the next node from the stack
     int sp = 0;
-    bool walkDone = true;   // nothing left to visit (parked triangles may still be waiting)
-    uint32_t pendK = 0, pendCnt = 0;
+    uint32_t pendK0 = 0, pendC0 = 0, pendK1 = 0, pendC1 = 0;
     trav::Hit best;
     uint32_t nodeVisits = 0, triTests = 0;
     unsigned long long totNodes = 0, totTris = 0, totRays = 0;
-    unsigned long long dbg[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+    auto push = [&](uint32_t node, float enter) {
+        const uint32_t bits = __float_as_uint(enter) >> 16;
+        if (sp < LDS_DEPTH) {
+            stNode[sp * THREADS] = node;
+            stEnter[sp * THREADS] = static_cast<unsigned short>(bits);
+        } else if (sp < STACK_DEPTH)
+            mySpill[(sp - LDS_DEPTH) * spillStride] = make_uint2(node, bits);
+        ++sp;
+    };
 
     while (true) {
+        // ---- retire finished rays, refill idle lanes ------------------------------------------------
+        if (finished) {
+            bool ok = true;
+            if (best.fi != 0xFFFFFFFFu)
+                ok = passes_parent(nodes, recs[best.k].parent, ray);
+            if (ok) {
+                tOut[rayIdx] = best.t;
+                baryOut[2ull * rayIdx] = best.bx;
+                baryOut[2ull * rayIdx + 1] = best.by;
+                primOut[rayIdx] = best.fi;
+            } else
+                exactList[atomicAdd(exactCount, 1u)] = rayIdx;
+            if (COUNT) {
+                totNodes += nodeVisits;
+                totTris += triTests;
+                ++totRays;
+            }
+            finished = false;
+        }
         const unsigned long long idleMask = __ballot(!active);
         if (idleMask != 0ull && !poolEmpty) {
             const uint32_t want = __popcll(idleMask);
@@ -299,7 +409,6 @@ __global__ __launch_bounds__(THREADS) void closest_hit_accel_kernel(
             base = __shfl(base, leader, 64);
             if (base + want >= rayNum || base + want < base)
                 poolEmpty = true;
-            if (COUNT) { dbg[0] += 1; dbg[1] += want; }
             if (!active) {
                 const uint32_t r = base + __popcll(idleMask & lanesBelow);
                 if (r < rayNum && r >= base) {
@@ -307,120 +416,152 @@ __global__ __launch_bounds__(THREADS) void closest_hit_accel_kernel(
                     const float *p = rays + 6ull * rayIdx;
                     ray.pos = {p[0], p[1], p[2]};
                     ray.dir = {p[3], p[4], p[5]};
-                    fray.pos = ray.pos;
-                    fray.inv = 1.f / ray.dir;
-                    exactOnly = !(fabsf(ray.dir.x) > 1e-18f && fabsf(ray.dir.y) > 1e-18f &&
-                                  fabsf(ray.dir.z) > 1e-18f && fabsf(fray.inv.x) < 1e18f &&
-                                  fabsf(fray.inv.y) < 1e18f && fabsf(fray.inv.z) < 1e18f);
-                    nodeVisits = triTests = 0;
-                    best.t = FloatMax;
-                    best.bx = best.by = 0.f;
-                    best.fi = best.k = 0xFFFFFFFFu;
-                    float tEnter, tExit;
-                    HitAABB(ray, rootBox, tEnter, tExit);
-                    cur = 0;
-                    sp = 0;
-                    pendCnt = 0;
-                    walkDone = tEnter > tExit;
-                    active = true;
+                    ray.inv = 1.f / ray.dir;
+                    const bool regular =
+                        fabsf(ray.dir.x) > 1e-18f && fabsf(ray.dir.y) > 1e-18f &&
+                        fabsf(ray.dir.z) > 1e-18f && fabsf(ray.inv.x) < 1e18f &&
+                        fabsf(ray.inv.y) < 1e18f && fabsf(ray.inv.z) < 1e18f;
+                    if (!regular) {
+                        exactList[atomicAdd(exactCount, 1u)] = rayIdx; // traced by the exact walker
+                    } else {
+                        offX = ray.dir.x < 0.f ? 16u : 0u;
+                        offY = ray.dir.y < 0.f ? 48u : 32u;
+                        offZ = ray.dir.z < 0.f ? 80u : 64u;
+                        nodeVisits = triTests = 0;
+                        best.t = FloatMax;
+                        best.bx = best.by = 0.f;
+                        best.fi = best.k = 0xFFFFFFFFu;
+                        float tEnter, tExit;
+                        HitAABB(Ray{ray.pos, ray.dir}, rootBox, tEnter, tExit);
+                        cur = 0;
+                        sp = 0;
+                        pendC0 = pendC1 = 0u;
+                        needNode = false;
+                        active = true;
+                        if (tEnter > tExit) { // misses the scene: retire at the next refill
+                            active = false;
+                            finished = true;
+                        }
+                    }
                 }
             }
         }
-        if (__ballot(active) == 0ull)
+        if (__ballot(active) == 0ull) {
+            if (__ballot(finished) != 0ull)
+                continue; // only retirements left
             break;
+        }
 
         while (true) {
-            const bool canStep = active && !walkDone && pendCnt == 0u;
-            if (COUNT) { dbg[2] += 1; const int c = __popcll(__ballot(canStep)); dbg[3] += (c != 0); dbg[4] += c; }
+            const float limit = best.t + trav::CULL_SLACK * best.t;
+            // ---- (A) take the next node from the stack ---------------------------------------------
+            if (active && needNode && (pendC0 | pendC1) == 0u) {
+                if (sp > 0) {
+                    --sp;
+                    uint32_t node = 0, enterBits = 0x7f80u;
+                    if (sp < LDS_DEPTH) {
+                        node = stNode[sp * THREADS];
+                        enterBits = stEnter[sp * THREADS];
+                    } else if (sp < STACK_DEPTH) {
+                        const uint2 e = mySpill[(sp - LDS_DEPTH) * spillStride];
+                        node = e.x;
+                        enterBits = e.y;
+                    }
+                    if (!(__uint_as_float(enterBits << 16) > limit)) {
+                        cur = node;
+                        needNode = false;
+                    }
+                } else { // walk over
+                    active = false;
+                    finished = true;
+                }
+            }
+            // ---- (B) visit a node ------------------------------------------------------------------
+            const bool canStep = active && !needNode && (pendC0 | pendC1) == 0u;
             if (canStep) {
-                uint32_t child[2], cnt[2];
-                AABB box[2];
-                load_wide(wide, cur, child, cnt, box);
+                // the record is 128-byte aligned: plane offsets go into the low address bits
+                const uint64_t base =
+                    reinterpret_cast<uint64_t>(node4Bytes) + (static_cast<uint64_t>(cur) << 7);
+                const uint32_t lo = static_cast<uint32_t>(base);
+                const uint64_t hi = base & 0xFFFFFFFF00000000ull;
+                const float4 nx = ld4(reinterpret_cast<const char *>(hi | (lo | offX)));
+                const float4 fx = ld4(reinterpret_cast<const char *>(hi | (lo | (offX ^ 16u))));
+                const float4 ny = ld4(reinterpret_cast<const char *>(hi | (lo | offY)));
+                const float4 fy = ld4(reinterpret_cast<const char *>(hi | (lo | (offY ^ 16u))));
+                const float4 nz = ld4(reinterpret_cast<const char *>(hi | (lo | offZ)));
+                const float4 fz = ld4(reinterpret_cast<const char *>(hi | (lo | (offZ ^ 16u))));
+                const uint4 ch = *reinterpret_cast<const uint4 *>(hi | (lo | 96u));
+                const uint4 cn = *reinterpret_cast<const uint4 *>(hi | (lo | 112u));
                 if (COUNT)
                     ++nodeVisits;
-                const float limit = best.t + trav::CULL_SLACK * best.t;
-                float en[2], ex[2];
-                bool hit[2];
+                const float nxs[4] = {nx.x, nx.y, nx.z, nx.w}, fxs[4] = {fx.x, fx.y, fx.z, fx.w};
+                const float nys[4] = {ny.x, ny.y, ny.z, ny.w}, fys[4] = {fy.x, fy.y, fy.z, fy.w};
+                const float nzs[4] = {nz.x, nz.y, nz.z, nz.w}, fzs[4] = {fz.x, fz.y, fz.z, fz.w};
+                const uint32_t child[4] = {ch.x, ch.y, ch.z, ch.w};
+                const uint32_t cnt[4] = {cn.x, cn.y, cn.z, cn.w};
+                float key[4];
+                uint32_t leafCnt[4];
 #pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    bool doubt;
-                    slab_fast(fray, box[s], en[s], ex[s], doubt);
-                    hit[s] = !(en[s] > ex[s]);
-                    if (cnt[s] != 0u)
-                        hit[s] = hit[s] || doubt; // grown leaf box: only ever a filter
-                    else if ((doubt || exactOnly) && !(child[s] & LEAF)) {
-                        HitAABB(ray, box[s], en[s], ex[s]);
-                        hit[s] = !(en[s] > ex[s]);
-                    }
-                    hit[s] = hit[s] && !(en[s] > limit);
+                for (int i = 0; i < 4; ++i) {
+                    const float en = fmaxf(fmaxf(fmaxf((nxs[i] - ray.pos.x) * ray.inv.x,
+                                                       (nys[i] - ray.pos.y) * ray.inv.y),
+                                                 (nzs[i] - ray.pos.z) * ray.inv.z),
+                                           0.f);
+                    const float ex = fminf(fminf((fxs[i] - ray.pos.x) * ray.inv.x,
+                                                 (fys[i] - ray.pos.y) * ray.inv.y),
+                                           (fzs[i] - ray.pos.z) * ray.inv.z);
+                    // conservative: keep the slot unless the miss is beyond the rounding margin
+                    const bool hit = (en <= __builtin_fmaf(fabsf(ex), SLAB_REL, ex + SLAB_ABS)) &
+                                     (en <= limit);
+                    const bool isLeaf = cnt[i] != 0u;
+                    leafCnt[i] = (hit & isLeaf) ? cnt[i] : 0u;
+                    key[i] = (hit & !isLeaf) ? en : __builtin_inff();
                 }
-                // leaf children: park their triangles. Two leaf children are neighbouring runs of the
-                // sorted order, so one (first, count) pair covers both.
-                const bool leafL = cnt[0] != 0u && hit[0], leafR = cnt[1] != 0u && hit[1];
-                if (leafL || leafR) {
-                    pendK = (leafL ? child[0] : child[1]) & LEAF_MASK;
-                    pendCnt = (leafL ? cnt[0] : 0u) + (leafR ? cnt[1] : 0u);
-                }
-                const bool goL = !(child[0] & LEAF) && hit[0];
-                const bool goR = !(child[1] & LEAF) && hit[1];
-                if (goL && goR && sp < STACK_DEPTH) {
-                    const bool leftFirst = !(en[1] < en[0]);
-                    const uint32_t farNode = leftFirst ? child[1] : child[0];
-                    const uint32_t farEnter = __float_as_uint(leftFirst ? en[1] : en[0]) >> 16;
-                    if (sp < LDS_DEPTH) {
-                        stNode[sp * THREADS] = farNode;
-                        stEnter[sp * THREADS] = static_cast<unsigned short>(farEnter);
-                    } else
-                        mySpill[(sp - LDS_DEPTH) * spillStride] = make_uint2(farNode, farEnter);
-                    ++sp;
-                    cur = leftFirst ? child[0] : child[1];
-                } else if (goL) {
-                    cur = child[0];
-                } else if (goR) {
-                    cur = child[1];
+                // leaf slots: park their triangles. Slots 0,1 (and 2,3) that are both leaves are
+                // neighbouring runs of the sorted order, so each pair parks one (first, count).
+                pendK0 = (leafCnt[0] ? child[0] : child[1]) & LEAF_MASK;
+                pendC0 = leafCnt[0] + leafCnt[1];
+                pendK1 = (leafCnt[2] ? child[2] : child[3]) & LEAF_MASK;
+                pendC1 = leafCnt[2] + leafCnt[3];
+                // internal slots: nearest first, the others stacked farthest first
+                uint32_t id[4] = {child[0], child[1], child[2], child[3]};
+                cswap(key[0], id[0], key[1], id[1]);
+                cswap(key[2], id[2], key[3], id[3]);
+                cswap(key[0], id[0], key[2], id[2]);
+                cswap(key[1], id[1], key[3], id[3]);
+                cswap(key[1], id[1], key[2], id[2]);
+                const float inf = __builtin_inff();
+                if (sp + 3 <= LDS_DEPTH) {
+                    // stores above the stack top are harmless: write all three, count the valid ones
+                    stNode[sp * THREADS] = id[3];
+                    stEnter[sp * THREADS] = static_cast<unsigned short>(__float_as_uint(key[3]) >> 16);
+                    sp += key[3] < inf;
+                    stNode[sp * THREADS] = id[2];
+                    stEnter[sp * THREADS] = static_cast<unsigned short>(__float_as_uint(key[2]) >> 16);
+                    sp += key[2] < inf;
+                    stNode[sp * THREADS] = id[1];
+                    stEnter[sp * THREADS] = static_cast<unsigned short>(__float_as_uint(key[1]) >> 16);
+                    sp += key[1] < inf;
                 } else {
-                    walkDone = true;
-                    while (sp > 0) {
-                        if (COUNT) { const unsigned long long m = __ballot(1); if (lane == __ffsll((long long)m) - 1) { dbg[5] += 1; dbg[6] += __popcll(m); } }
-                        --sp;
-                        uint32_t node, enterBits;
-                        if (sp < LDS_DEPTH) {
-                            node = stNode[sp * THREADS];
-                            enterBits = stEnter[sp * THREADS];
-                        } else {
-                            const uint2 e = mySpill[(sp - LDS_DEPTH) * spillStride];
-                            node = e.x;
-                            enterBits = e.y;
-                        }
-                        if (!(__uint_as_float(enterBits << 16) > limit)) {
-                            cur = node;
-                            walkDone = false;
-                            break;
-                        }
-                    }
+                    if (key[3] < inf)
+                        push(id[3], key[3]);
+                    if (key[2] < inf)
+                        push(id[2], key[2]);
+                    if (key[1] < inf)
+                        push(id[1], key[1]);
                 }
+                cur = id[0];
+                needNode = !(key[0] < inf);
             }
-            // triangle phase, when it pays
-            const int parked = __popcll(__ballot(pendCnt != 0u));
-            const int stepping = __popcll(__ballot(active && !walkDone && pendCnt == 0u));
+            // ---- (C) triangle phase, when it pays --------------------------------------------------
+            const int parked = __popcll(__ballot((pendC0 | pendC1) != 0u));
+            const int stepping = __popcll(__ballot(active && (pendC0 | pendC1) == 0u));
             if (parked != 0 && (parked >= PARK_MIN || stepping < STEP_MIN)) {
-                if (COUNT) { dbg[7] += 1; dbg[8] += parked; }
-                if (pendCnt != 0u) {
-                    test_run<COUNT>(recs, ray, pendK, pendCnt, best, triTests);
-                    pendCnt = 0u;
+                if ((pendC0 | pendC1) != 0u) {
+                    test_run<COUNT>(recs, ray, pendK0, pendC0, best, triTests);
+                    test_run<COUNT>(recs, ray, pendK1, pendC1, best, triTests);
+                    pendC0 = pendC1 = 0u;
                 }
-            }
-            if (active && walkDone && pendCnt == 0u) {
-                tOut[rayIdx] = best.t;
-                baryOut[2ull * rayIdx] = best.bx;
-                baryOut[2ull * rayIdx + 1] = best.by;
-                primOut[rayIdx] = best.fi;
-                if (COUNT) {
-                    totNodes += nodeVisits;
-                    totTris += triTests;
-                    ++totRays;
-                }
-                active = false;
             }
             const int alive = __popcll(__ballot(active));
             if (alive == 0 || (!poolEmpty && alive < REFILL_BELOW))
@@ -434,11 +575,6 @@ __global__ __launch_bounds__(THREADS) void closest_hit_accel_kernel(
             totTris += __shfl_xor(totTris, o, 64);
             totRays += __shfl_xor(totRays, o, 64);
         }
-        for (int i = 0; i < 10; ++i) {
-            unsigned long long v = dbg[i];
-            if (i == 5 || i == 6) for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-            if (lane == 0) atomicAdd(&counters[4 + i], v);
-        }
         if (lane == 0) {
             atomicAdd(&counters[0], totNodes);
             atomicAdd(&counters[1], totTris);
@@ -448,18 +584,20 @@ __global__ __launch_bounds__(THREADS) void closest_hit_accel_kernel(
 }
 
 struct TraceWs {
-    size_t counter, spill, keysA, keysB, valsA, valsB, sortWs, sortWsBytes, total;
+    size_t counter, spill, exactList, keysA, keysB, valsA, valsB, sortWs, sortWsBytes, total;
 };
 inline TraceWs trace_ws(uint32_t rayNum) {
     TraceWs w;
     Carver c;
-    w.counter = c.take(256);
+    const size_t n = rayNum ? rayNum : 1;
+    w.counter = c.take(256); // [0] ray queue head, [16] exact-list length, [32] exact queue head
     w.spill = c.take(sizeof(uint2) * MAX_GRID * THREADS * (STACK_DEPTH - LDS_DEPTH));
-    w.keysA = c.take(4ull * rayNum);
-    w.keysB = c.take(4ull * rayNum);
-    w.valsA = c.take(4ull * rayNum);
-    w.valsB = c.take(4ull * rayNum);
-    w.sortWsBytes = kk_sort_workspace_bytes(rayNum ? rayNum : 1);
+    w.exactList = c.take(4 * n);
+    w.keysA = c.take(4 * n);
+    w.keysB = c.take(4 * n);
+    w.valsA = c.take(4 * n);
+    w.valsB = c.take(4 * n);
+    w.sortWsBytes = kk_sort_workspace_bytes(static_cast<uint32_t>(n));
     w.sortWs = c.take(w.sortWsBytes);
     w.total = c.off;
     return w;
@@ -491,8 +629,8 @@ extern "C" int kk_trace_accel_build(const kk_lbvh_device_data *d_lbvh, const flo
     pack_tris_kernel<<<div_up(face_num, THREADS), THREADS, 0, stream>>>(d_lbvh, d_positions,
                                                                         d_face_pos_idx, recs, face_num);
     KK_LAUNCH_CHECK();
-    make_wide_kernel<<<div_up(nodeNum, THREADS), THREADS, 0, stream>>>(
-        d_lbvh, recs, reinterpret_cast<WideNode *>(b + l.nodes), reinterpret_cast<Header *>(b + l.header),
+    make_node4_kernel<<<div_up(nodeNum, THREADS), THREADS, 0, stream>>>(
+        d_lbvh, recs, reinterpret_cast<Node4 *>(b + l.nodes), reinterpret_cast<Header *>(b + l.header),
         nodeNum);
     KK_LAUNCH_CHECK();
     return KK_OK;
@@ -502,14 +640,18 @@ extern "C" size_t kk_closest_hit_accel_workspace_bytes(uint32_t ray_num) {
     return kk::accel::trace_ws(ray_num).total;
 }
 
-extern "C" int kk_closest_hit_accel(const void *d_accel, uint32_t face_num,
-                                    uint32_t compacted_face_num, const float *d_rays,
-                                    uint32_t ray_num, float *d_t, float *d_bary, uint32_t *d_prim,
-                                    uint32_t flags, unsigned long long *d_counters, void *d_workspace,
+extern "C" int kk_closest_hit_accel(const void *d_accel, const kk_lbvh_device_data *d_lbvh,
+                                    const float *d_positions, const uint32_t *d_face_pos_idx,
+                                    uint32_t face_num, uint32_t compacted_face_num,
+                                    const float *d_rays, uint32_t ray_num, float *d_t, float *d_bary,
+                                    uint32_t *d_prim, uint32_t flags,
+                                    unsigned long long *d_counters, void *d_workspace,
                                     size_t workspace_bytes, void *stream_) {
     using namespace kk;
     using namespace kk::accel;
-    KK_REQUIRE(d_accel && d_rays && d_t && d_bary && d_prim && d_workspace, "null pointer");
+    KK_REQUIRE(d_accel && d_lbvh && d_positions && d_face_pos_idx && d_rays && d_t && d_bary &&
+                   d_prim && d_workspace,
+               "null pointer");
     KK_REQUIRE(face_num > 0 && compacted_face_num > 0 && compacted_face_num <= face_num,
                "tree sizes out of range");
     KK_REQUIRE((flags & ~static_cast<uint32_t>(KK_TRACE_UNSORTED)) == 0, "unknown flag");
@@ -521,7 +663,7 @@ extern "C" int kk_closest_hit_accel(const void *d_accel, uint32_t face_num,
     const Layout l = layout(face_num, compacted_face_num);
     const char *ab = static_cast<const char *>(d_accel);
     const auto *hdr = reinterpret_cast<const Header *>(ab + l.header);
-    const auto *wide = reinterpret_cast<const WideNode *>(ab + l.nodes);
+    const auto *node4 = reinterpret_cast<const Node4 *>(ab + l.nodes);
     const auto *recs = reinterpret_cast<const TriRec *>(ab + l.tris);
     char *b = static_cast<char *>(d_workspace);
     uint32_t *rayCounter = reinterpret_cast<uint32_t *>(b + w.counter);
@@ -531,25 +673,31 @@ extern "C" int kk_closest_hit_accel(const void *d_accel, uint32_t face_num,
     if (!(flags & KK_TRACE_UNSORTED)) {
         auto *keysA = reinterpret_cast<uint32_t *>(b + w.keysA);
         auto *valsA = reinterpret_cast<uint32_t *>(b + w.valsA);
+        auto *valsB = reinterpret_cast<uint32_t *>(b + w.valsB);
         ray_keys_kernel<<<div_up(ray_num, THREADS), THREADS, 0, stream>>>(hdr, d_rays, ray_num, keysA);
         KK_LAUNCH_CHECK();
-        int rc = rsort::sort_pairs(keysA, reinterpret_cast<uint32_t *>(b + w.keysB), valsA,
-                                   reinterpret_cast<uint32_t *>(b + w.valsB), true, ray_num,
-                                   b + w.sortWs, w.sortWsBytes, stream, nullptr);
+        int rc = rsort::sort_pairs(keysA, reinterpret_cast<uint32_t *>(b + w.keysB), valsA, valsB, true,
+                                   ray_num, b + w.sortWs, w.sortWsBytes, stream, nullptr, KEY_PASSES);
         if (rc != KK_OK)
             return rc;
-        order = valsA;
+        order = (KEY_PASSES & 1) ? valsB : valsA;
     }
     uint32_t grid = div_up(ray_num, THREADS);
     if (grid > MAX_GRID)
         grid = MAX_GRID;
     uint2 *spill = reinterpret_cast<uint2 *>(b + w.spill);
+    int tune[3] = {REFILL_BELOW_D, PARK_MIN_D, STEP_MIN_D};
+    if (const char *e = getenv("KK_TRACE_TUNE")) sscanf(e, "%d,%d,%d", &tune[0], &tune[1], &tune[2]);
+    uint32_t *exactList = reinterpret_cast<uint32_t *>(b + w.exactList);
     if (d_counters)
         closest_hit_accel_kernel<true><<<grid, THREADS, 0, stream>>>(
-            hdr, wide, recs, d_rays, order, ray_num, d_t, d_bary, d_prim, rayCounter, spill, d_counters);
+            hdr, node4, recs, d_rays, order, ray_num, d_t, d_bary, d_prim, rayCounter, exactList,
+            rayCounter + 16, spill, d_counters, tune[0], tune[1], tune[2]);
     else
         closest_hit_accel_kernel<false><<<grid, THREADS, 0, stream>>>(
-            hdr, wide, recs, d_rays, order, ray_num, d_t, d_bary, d_prim, rayCounter, spill, nullptr);
+            hdr, node4, recs, d_rays, order, ray_num, d_t, d_bary, d_prim, rayCounter, exactList,
+            rayCounter + 16, spill, nullptr, tune[0], tune[1], tune[2]);
     KK_LAUNCH_CHECK();
-    return KK_OK;
+    return trav::launch_listed(d_lbvh, d_positions, d_face_pos_idx, d_rays, d_t, d_bary, d_prim,
+                               rayCounter + 32, exactList, rayCounter + 16, stream);
 }

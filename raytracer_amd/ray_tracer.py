@@ -33,12 +33,14 @@ def closest_hit(lbvh: LBVH, rays, count: bool = False, out=None, layout: str = "
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     else:
         t, bary, prim, ws = out
-    counters = torch.zeros(16, dtype=torch.int64, device=dev) if count else None
+    counters = torch.zeros(4, dtype=torch.int64, device=dev) if count else None
     with torch.cuda.device(dev):
         if layout == "trace":
             accel = lbvh.trace_accel()
             N, M = lbvh._accel_sizes
-            _lib.check(l.kk_closest_hit_accel(accel.data_ptr(), N, M, d_rays.data_ptr(), R, t.data_ptr(),
+            _lib.check(l.kk_closest_hit_accel(accel.data_ptr(), lbvh.GetDeivceDataDevicePtr(),
+                                              lbvh.d_positions.data_ptr(), lbvh.d_face_pos_idx.data_ptr(),
+                                              N, M, d_rays.data_ptr(), R, t.data_ptr(),
                                               bary.data_ptr(), prim.data_ptr(),
                                               0 if sort else _lib.KK_TRACE_UNSORTED,
                                               counters.data_ptr() if count else None, ws.data_ptr(),
@@ -53,7 +55,7 @@ def closest_hit(lbvh: LBVH, rays, count: bool = False, out=None, layout: str = "
                                         _lib.current_stream_ptr()), "kk_closest_hit")
     if count:
         c = counters.cpu().numpy()
-        return t, bary, prim, {"node_fetches": int(c[0]), "tri_tests": int(c[1]), "rays": int(c[2]), "dbg": c[4:14].tolist()}
+        return t, bary, prim, {"node_fetches": int(c[0]), "tri_tests": int(c[1]), "rays": int(c[2])}
     return t, bary, prim
 
 
