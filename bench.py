@@ -5,7 +5,9 @@
 
 One "step" is one pass of the closest-hit path over one batch of synthetic input: 2,097,152 incoherent
 rays (seed 0x5EED0002) traced through the LBVH of the 10 M-triangle soup (seed 0x5EED0001); the rays
-and the tree are resident in HBM before the timed region. The same run also times the LBVH build of
+and the tree (with its trace-side repacking) are resident in HBM before the timed region. A step
+orders the rays (Morton keys + radix sort) and traces them; the dominant kernel's own duration is
+measured in a second loop that reuses the order. The same run also times the LBVH build of
 that soup (ms per 10 M triangles) and, when the volume path is built, the DVR frame rate; they are
 reported in the same JSON line beside the headline value.
 
@@ -99,11 +101,23 @@ def main():
     # ---- rays: each rank owns rays [rank*R, (rank+1)*R) of the stream --------------------------------
     rays_h = syn.incoherent_rays(R, first=rank * R)
     rays = torch.from_numpy(rays_h).to(dev)
-    l_out = None
+    accel_ms = None
+    bvh.trace_accel()
+    if rank == 0:
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        times = []
+        for i in range(2 + 5):
+            ev[0].record()
+            bvh.trace_accel(rebuild=True)
+            ev[1].record()
+            torch.cuda.synchronize()
+            if i >= 2:
+                times.append(ev[0].elapsed_time(ev[1]))
+        accel_ms = float(np.median(times))
     t, bary, prim, counters = closest_hit(bvh, rays, count=True)
     torch.cuda.synchronize()
     from raytracer_amd import _lib
-    ws = torch.empty(_lib.lib().kk_closest_hit_workspace_bytes(), dtype=torch.uint8, device=dev)
+    ws = torch.empty(_lib.lib().kk_closest_hit_accel_workspace_bytes(R), dtype=torch.uint8, device=dev)
     l_out = (t, bary, prim, ws)
 
     for _ in range(W):
@@ -111,23 +125,27 @@ def main():
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
-    ev0.record()
     for _ in range(K):
         closest_hit(bvh, rays, out=l_out)
-    ev1.record()
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
     wall = time.perf_counter() - t0
-    kernel_ms = ev0.elapsed_time(ev1) / K  # HIP events on the launch stream: average launch duration
     if dist:
         tt = torch.tensor([wall], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         wall = float(tt.item())
     ms_per_step = wall * 1e3 / K
     value = world * R / (ms_per_step * 1e-3) / 1e6
+    # the trace kernel alone (same rays, order kept from the last step): HIP events on the launch stream
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for _ in range(K):
+        closest_hit(bvh, rays, out=l_out, reuse_order=True)
+    ev1.record()
+    torch.cuda.synchronize()
+    kernel_ms = ev0.elapsed_time(ev1) / K
 
     dvr = None
     if not args.no_dvr:
@@ -139,16 +157,16 @@ def main():
             dist.destroy_process_group()
         return
 
-    # ---- roofline of the dominant kernel (closest_hit_kernel) ---------------------------------------
-    # algorithmic bytes per launch: 32 B per node box fetched + 48 B per triangle tested (12 B indices
-    # + 36 B vertices) + 24 B ray in + 16 B hit out, counted by the kernel's own work counters
-    alg_bytes = 32 * counters["node_fetches"] + 48 * counters["tri_tests"] + (24 + 16) * R
+    # ---- roofline of the dominant kernel (closest_hit_accel_kernel) ---------------------------------
+    # algorithmic bytes per launch: 64 B per node record visited + 48 B per triangle record tested +
+    # 4 B order index + 24 B ray in + 16 B hit out, counted by the kernel's own work counters
+    alg_bytes = 64 * counters["node_fetches"] + 48 * counters["tri_tests"] + (4 + 24 + 16) * R
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
-                "kernel": "closest_hit_kernel", "avg_launch_ms": round(kernel_ms, 4),
+                "kernel": "closest_hit_accel_kernel", "avg_launch_ms": round(kernel_ms, 4),
                 "algorithmic_bytes_per_launch": int(alg_bytes),
-                "node_fetches_per_ray": round(counters["node_fetches"] / R, 2),
+                "node_records_per_ray": round(counters["node_fetches"] / R, 2),
                 "tri_tests_per_ray": round(counters["tri_tests"] / R, 2)}
     pmc = os.path.join(ROOT, "profiles", "r01_closest_hit_pmc.json")
     if os.path.exists(pmc):
@@ -169,6 +187,7 @@ def main():
     }
     if build_ms is not None:
         gbps = LBVH_BYTES_PER_TRI * N / (build_ms * 1e-3) / 1e9
+        out["trace_accel_build_ms"] = round(accel_ms, 4)
         out["lbvh_build"] = {"ms": round(build_ms, 4), "ms_per_10Mtri": round(build_ms * 1e7 / N, 4),
                              "bytes_per_tri": LBVH_BYTES_PER_TRI, "achieved_GBps": round(gbps, 1),
                              "frac_of_hbm_peak": round(gbps / HBM_PEAK_GBPS, 4)}

@@ -140,31 +140,33 @@ int kk_closest_hit(const kk_lbvh_device_data *d_lbvh, const float *d_positions,
 
 /* ---- trace-side layout of a built tree (no counterpart in the reference: its rayCastLBVH walks the
  * build's own arrays, src/ray_tracer/ray_tracer_render.cu:192-270). kk_trace_accel_build repacks the
- * binary tree kk_lbvh_build produced: one 128-byte record per internal node holding the ids and boxes
- * of its four grandchildren (a leaf's box is the box of its triangles grown by 1e-5 of the scene's
- * largest coordinate) and one 48-byte record per sorted triangle (three vertices, face index, index
- * of the leaf's parent node). kk_closest_hit_accel gives the same (t, bary, prim) as kk_closest_hit:
- * a triangle counts exactly when the ray passes the reference's slab test of the leaf's parent box
- * (which, boxes being exact unions, implies the tests of all nodes above it) and the triangle
- * arithmetic is the same; rays with a zero direction component are traced by kk_closest_hit's walk.
- * Rays are traced in Morton order of their origins unless KK_TRACE_UNSORTED is given; outputs are
- * indexed like the input. The accel keeps a pointer to d_lbvh's internal_nodes: rebuild it when the
+ * binary tree kk_lbvh_build produced: one 64-byte record per internal node holding the ids and the
+ * 8-bit quantised (outward-rounded) boxes of its four grandchildren (a leaf's box is the box of its
+ * triangles grown by 1e-5 of the scene's largest coordinate), one 48-byte record per sorted triangle
+ * (three vertices, face index, index of the leaf's parent node) and each node's parent index.
+ * kk_closest_hit_accel gives the same (t, bary, prim) as kk_closest_hit: a triangle counts exactly
+ * when the ray passes the reference's slab test of the leaf's parent box (which, boxes being exact
+ * unions, implies the tests of all nodes above it; for rays with a zero direction component every
+ * box up to the root is tested) and the triangle arithmetic is the same.
+ * Rays are traced in Morton order of their origins unless a flag says otherwise; outputs are indexed
+ * like the input. The accel keeps a pointer to d_lbvh's internal_nodes: rebuild it when the
  * tree's arrays move. */
-enum { KK_TRACE_UNSORTED = 1u };
+enum {
+    KK_TRACE_UNSORTED = 1u,   /* trace in input order */
+    KK_TRACE_REUSE_ORDER = 2u /* the same rays as the previous call with this workspace: keep its order */
+};
 size_t kk_trace_accel_bytes(uint32_t face_num, uint32_t compacted_face_num);
 /* d_accel: 256-byte aligned device buffer of kk_trace_accel_bytes(). */
 int kk_trace_accel_build(const kk_lbvh_device_data *d_lbvh, const float *d_positions,
                          const uint32_t *d_face_pos_idx, uint32_t face_num,
                          uint32_t compacted_face_num, void *d_accel, size_t accel_bytes, void *stream);
 size_t kk_closest_hit_accel_workspace_bytes(uint32_t ray_num);
-/* d_counters (optional, uint64[4], zeroed by the caller): 128-byte node records visited, triangles
- * tested, rays traced (rays handed to the exact walk are not counted). */
-int kk_closest_hit_accel(const void *d_accel, const kk_lbvh_device_data *d_lbvh,
-                         const float *d_positions, const uint32_t *d_face_pos_idx, uint32_t face_num,
-                         uint32_t compacted_face_num, const float *d_rays, uint32_t ray_num,
-                         float *d_t, float *d_bary, uint32_t *d_prim, uint32_t flags,
-                         unsigned long long *d_counters, void *d_workspace, size_t workspace_bytes,
-                         void *stream);
+/* d_counters (optional, uint64[4], zeroed by the caller): 64-byte node records visited, triangles
+ * tested, rays traced. */
+int kk_closest_hit_accel(const void *d_accel, uint32_t face_num, uint32_t compacted_face_num,
+                         const float *d_rays, uint32_t ray_num, float *d_t, float *d_bary,
+                         uint32_t *d_prim, uint32_t flags, unsigned long long *d_counters,
+                         void *d_workspace, size_t workspace_bytes, void *stream);
 
 /* ================================================================================================
  * Path 1c: path tracer  --  kouek::RayTracer::RayTracer::Render(surface, size, RenderTarget::Scene)

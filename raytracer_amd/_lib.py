@@ -67,6 +67,7 @@ assert C.sizeof(VdbParam) == 128 and C.sizeof(VdbDeviceData) == 176 and C.sizeof
 KK_LBVH_KEEP_STAGES = 1
 KK_TRAVERSE_ORDERED = 0
 KK_TRACE_UNSORTED = 1
+KK_TRACE_REUSE_ORDER = 2
 
 _lib = None
 
@@ -94,7 +95,7 @@ def _declare(l):
     l.kk_trace_accel_build.argtypes = [vp, vp, vp, u32, u32, vp, sz, vp]
     l.kk_closest_hit_accel_workspace_bytes.restype = sz
     l.kk_closest_hit_accel_workspace_bytes.argtypes = [u32]
-    l.kk_closest_hit_accel.argtypes = [vp, vp, vp, vp, u32, u32, vp, u32, vp, vp, vp, u32, vp, vp, sz, vp]
+    l.kk_closest_hit_accel.argtypes = [vp, u32, u32, vp, u32, vp, vp, vp, u32, vp, vp, sz, vp]
     l.kk_pt_render_sample.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, C.c_float, u32, vp]
     l.kk_rng_uniforms.argtypes = [u32, u32, u32, u32, vp, vp]
     for sfx in ("u8", "u16"):

@@ -22,27 +22,21 @@
 // more than the reference, never less). A triangle whose Moeller-Trumbore test (same arithmetic as
 // 3rd/glm/gtx/intersect.inl:28-94) beats the best hit is accepted only after the slab test of its
 // leaf's parent box: decided by the fast test when that is outside its error margin, by the
-// reference's division form otherwise. Rays with a (near-)zero direction component, where plane
-// distances become inf / NaN and the containment argument does not hold, are handed to the exact
-// walker of traverse.hip through a list.
+// reference's division form otherwise. For a ray with a (near-)zero direction component plane
+// distances become inf / NaN and the containment argument does not hold: such a ray walks with
+// +-1e18 in place of the infinite reciprocal (still a superset of the reference's visits) and accepts
+// a hit only after the reference's slab test of EVERY node from the leaf's parent up to the root.
 // Rays are traced in Morton order of their origins (radix sort of (key, index)); outputs are written
 // at the ray's own index.
 #include "kk_host.h"
 #include "kk_math.h"
 #include "traverse.h"
-#include <stdlib.h>
 
 namespace kk {
 namespace rsort {
 int sort_pairs(uint32_t *keysA, uint32_t *keysB, uint32_t *valsA, uint32_t *valsB, bool iota,
                uint32_t n, void *ws, size_t wsBytes, hipStream_t stream, uint32_t **errorFlagOut,
                int passes);
-}
-namespace trav {
-int launch_listed(const kk_lbvh_device_data *lbvh, const float *positions, const uint32_t *tri,
-                  const float *rays, float *tOut, float *baryOut, uint32_t *primOut,
-                  uint32_t *rayCounter, const uint32_t *list, const uint32_t *listCount,
-                  hipStream_t stream);
 }
 extern "C" size_t kk_sort_workspace_bytes(uint32_t n);
 
@@ -55,12 +49,18 @@ constexpr int THREADS = 256;
 constexpr float LEAF_PAD = 1e-5f; // leaf boxes grow by this fraction of the scene's largest coordinate
 constexpr uint32_t EMPTY = 0xFFFFFFFFu;
 
-struct alignas(128) Node4 {
-    float plane[6][4]; // minx[4] maxx[4] miny[4] maxy[4] minz[4] maxz[4]
+// 64 bytes: the four slot boxes are 8-bit offsets from `origin` in units of 2^exp per axis, rounded
+// outwards by one extra unit, so a dequantised box always contains the float box it stands for.
+struct alignas(64) Node4 {
+    float origin[3];
+    int8_t exp[3];
+    uint8_t pad;
+    uint8_t q[6][4];   // minx[4] maxx[4] miny[4] maxy[4] minz[4] maxz[4]
     uint32_t child[4]; // binary node index | LEAF + first sorted position | EMPTY
-    uint32_t cnt[4];   // triangles of a leaf slot, 0 otherwise
+    uint16_t cnt[4];   // triangles of a leaf slot (CNT_LONG: read the count from the first TriRec)
 };
-static_assert(sizeof(Node4) == 128, "one cache line");
+static_assert(sizeof(Node4) == 64, "half a cache line");
+constexpr uint32_t CNT_LONG = 0xFFFFu;
 
 struct alignas(16) TriRec {
     float v0[3];
@@ -68,7 +68,7 @@ struct alignas(16) TriRec {
     float v1[3];
     uint32_t parent; // binary node whose child is this triangle's leaf
     float v2[3];
-    uint32_t pad;
+    uint32_t run; // in the first record of a leaf's run: the number of triangles in the run
 };
 static_assert(sizeof(TriRec) == 48, "three 16-byte loads");
 
@@ -79,7 +79,7 @@ struct alignas(256) Header {
 };
 
 struct Layout {
-    size_t header, nodes, tris, total;
+    size_t header, nodes, tris, parents, total;
 };
 inline Layout layout(uint32_t faceNum, uint32_t compactedNum) {
     Layout l;
@@ -88,6 +88,7 @@ inline Layout layout(uint32_t faceNum, uint32_t compactedNum) {
     l.header = c.take(sizeof(Header));
     l.nodes = c.take(sizeof(Node4) * static_cast<size_t>(nodeNum));
     l.tris = c.take(sizeof(TriRec) * static_cast<size_t>(faceNum));
+    l.parents = c.take(sizeof(uint32_t) * static_cast<size_t>(nodeNum)); // parent of each binary node
     l.total = c.off;
     return l;
 }
@@ -141,6 +142,7 @@ __device__ __forceinline__ Slot leaf_slot(const kk_lbvh_device_data *__restrict_
         s.box.Expand(F3(r.v2[0], r.v2[1], r.v2[2]));
         r.parent = parent; // every writer of this word writes the same value
     }
+    recs[k0].run = k1 - k0;
     s.box.minPos = s.box.minPos - pad;
     s.box.maxPos = s.box.maxPos + pad;
     s.child = LEAF | k0;
@@ -150,7 +152,8 @@ __device__ __forceinline__ Slot leaf_slot(const kk_lbvh_device_data *__restrict_
 
 __global__ __launch_bounds__(THREADS) void make_node4_kernel(
     const kk_lbvh_device_data *__restrict__ lbvh, TriRec *__restrict__ recs,
-    Node4 *__restrict__ out, Header *__restrict__ hdr, uint32_t nodeNum) {
+    Node4 *__restrict__ out, uint32_t *__restrict__ parents, Header *__restrict__ hdr,
+    uint32_t nodeNum) {
     const uint32_t n = blockIdx.x * THREADS + threadIdx.x;
     if (n >= nodeNum)
         return;
@@ -174,6 +177,12 @@ __global__ __launch_bounds__(THREADS) void make_node4_kernel(
     }
     const trav::NodeData me = trav::load_node(nodes, n);
     const uint32_t ch[2] = {me.lft, me.rht};
+    if (n == 0)
+        parents[0] = EMPTY;
+    if (!(ch[0] & LEAF))
+        parents[ch[0]] = n;
+    if (!(ch[1] & LEAF))
+        parents[ch[1]] = n;
     Slot slot[4];
     for (int s = 0; s < 2; ++s) {
         const uint32_t c = ch[s];
@@ -196,19 +205,38 @@ __global__ __launch_bounds__(THREADS) void make_node4_kernel(
             }
         }
     }
+    AABB u = AABB::Initial();
+    for (int i = 0; i < 4; ++i)
+        if (slot[i].child != EMPTY)
+            u.Expand(slot[i].box);
     Node4 w;
-    for (int i = 0; i < 4; ++i) {
-        for (int a = 0; a < 3; ++a) {
-            w.plane[2 * a][i] = slot[i].box.minPos[a];
-            w.plane[2 * a + 1][i] = slot[i].box.maxPos[a];
+    for (int a = 0; a < 3; ++a) {
+        const float ext = u.maxPos[a] - u.minPos[a];
+        const float r = ext / 253.f;
+        int e = r > 0.f ? ilogbf(r) + 1 : -100; // 2^e > ext / 253: offsets stay below 254
+        e = e < -100 ? -100 : (e > 100 ? 100 : e);
+        const float inv = ldexpf(1.f, -e);
+        w.origin[a] = u.minPos[a];
+        w.exp[a] = static_cast<int8_t>(e);
+        for (int i = 0; i < 4; ++i) {
+            float lo = 255.f, hi = 0.f;
+            if (slot[i].child != EMPTY) {
+                lo = fmaxf(floorf((slot[i].box.minPos[a] - u.minPos[a]) * inv) - 1.f, 0.f);
+                hi = fminf(ceilf((slot[i].box.maxPos[a] - u.minPos[a]) * inv) + 1.f, 255.f);
+            }
+            w.q[2 * a][i] = static_cast<uint8_t>(lo);
+            w.q[2 * a + 1][i] = static_cast<uint8_t>(hi);
         }
+    }
+    w.pad = 0;
+    for (int i = 0; i < 4; ++i) {
         w.child[i] = slot[i].child;
-        w.cnt[i] = slot[i].cnt;
+        w.cnt[i] = static_cast<uint16_t>(slot[i].cnt < CNT_LONG ? slot[i].cnt : CNT_LONG);
     }
     uint4 *o = reinterpret_cast<uint4 *>(out + n);
     const uint4 *src = reinterpret_cast<const uint4 *>(&w);
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < 4; ++i)
         o[i] = src[i];
 }
 
@@ -250,9 +278,9 @@ __global__ __launch_bounds__(THREADS) void ray_keys_kernel(const Header *__restr
 
 constexpr int STACK_DEPTH = 48; // <= 3 pushes per visited record, <= 15 records deep (tree depth <= 30)
 constexpr int LDS_DEPTH = 20;   // entries kept in LDS; deeper ones (rare) live in the workspace
-constexpr int REFILL_BELOW_D = 40;
-constexpr int PARK_MIN_D = 16; // run the triangle code once this many lanes wait for it ...
-constexpr int STEP_MIN_D = 24; // ... or fewer than this many lanes can still step
+constexpr int REFILL_BELOW = 40;
+constexpr int PARK_MIN = 16; // run the triangle code once this many lanes wait for it ...
+constexpr int STEP_MIN = 24; // ... or fewer than this many lanes can still step
 constexpr uint32_t MAX_GRID = 1280; // 30 KB of LDS and < 96 VGPRs: five workgroups per CU
 // A product (b - o) * (1 / d) is within 3 * 2^-24 of the reference's fl((b - o) / d) (one rounding
 // each in 1 / d, the product, and the quotient it stands for); min / max keep the bound.
@@ -285,11 +313,33 @@ __device__ __forceinline__ bool passes_parent(const kk_lbvh_node *__restrict__ n
     return !(tEnter > tExit);
 }
 
-// Triangles [k0, k0 + n) against the ray. A better hit is taken at once; whether its leaf's parent box
-// passes the reference's slab test is checked once, for the final hit, when the ray retires.
+// Does `r` pass the reference's slab test of node `p` and of every node above it?
+__device__ __forceinline__ bool passes_chain(const kk_lbvh_node *__restrict__ nodes,
+                                             const uint32_t *__restrict__ parents, uint32_t p,
+                                             const RayState &r) {
+    const Ray ray{r.pos, r.dir};
+    while (p != EMPTY) {
+        const trav::NodeData nd = trav::load_node(nodes, p);
+        float tEnter, tExit;
+        HitAABB(ray, nd.box, tEnter, tExit);
+        if (tEnter > tExit)
+            return false;
+        p = parents[p];
+    }
+    return true;
+}
+
+enum : uint32_t { MODE_FAST = 0, MODE_CAREFUL = 1, MODE_CHAIN = 2 };
+
+// Triangles [k0, k0 + n) against the ray. Normally a better hit is taken at once and whether its
+// leaf's parent box passes the reference's slab test is checked once, for the final hit, when the ray
+// retires (MODE_FAST). A ray being re-traced after that check failed checks every hit it takes
+// (MODE_CAREFUL); a ray with a zero direction component checks the whole chain of boxes (MODE_CHAIN).
 template <bool COUNT>
-__device__ __forceinline__ void test_run(const TriRec *__restrict__ recs, const RayState &r,
-                                         uint32_t k0, uint32_t n, trav::Hit &best,
+__device__ __forceinline__ void test_run(const TriRec *__restrict__ recs,
+                                         const kk_lbvh_node *__restrict__ nodes,
+                                         const uint32_t *__restrict__ parents, const RayState &r,
+                                         uint32_t mode, uint32_t k0, uint32_t n, trav::Hit &best,
                                          uint32_t &triTests) {
     const Ray ray{r.pos, r.dir};
     for (uint32_t k = k0; k < k0 + n; ++k) {
@@ -303,11 +353,14 @@ __device__ __forceinline__ void test_run(const TriRec *__restrict__ recs, const 
         if (COUNT)
             ++triTests;
         if (t >= 0.f && (t < best.t || (t == best.t && k < best.k))) {
-            best.t = t;
-            best.bx = bx;
-            best.by = by;
-            best.fi = a.w;
-            best.k = k;
+            if (mode == MODE_FAST || (mode == MODE_CAREFUL ? passes_parent(nodes, b.w, r)
+                                                           : passes_chain(nodes, parents, b.w, r))) {
+                best.t = t;
+                best.bx = bx;
+                best.by = by;
+                best.fi = a.w;
+                best.k = k;
+            }
         }
     }
 }
@@ -324,19 +377,19 @@ __device__ __forceinline__ void cswap(float &ka, uint32_t &ia, float &kb, uint32
 // lane is at the same place in the code: (A) lanes that need a node pop one stack entry, (B) lanes
 // with a node visit it, (C) when enough lanes have parked leaf triangles (or too few can still step)
 // the parked lanes test them. A finished ray waits until the wave refills: then all finished lanes
-// check their final hit against its leaf's parent box, write their result (or hand the ray to the
-// exact walker if the check fails) and take new rays with one ballot + one atomic per wave.
+// check their final hit against its leaf's parent box, write their result (or start the ray again
+// in careful mode if the check fails) and take new rays with one ballot + one atomic per wave.
 //
 // Taking a better triangle hit without checking its parent box first is safe: the limit that prunes
 // the walk is never below the final t, so nothing closer is skipped; if the final hit itself fails
-// the check, the ray is redone exactly.
+// the check, the lane walks the ray again with every hit checked as it is taken.
 template <bool COUNT>
-__global__ __launch_bounds__(THREADS) void closest_hit_accel_kernel(
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(5, 5))) void closest_hit_accel_kernel(
     const Header *__restrict__ hdr, const Node4 *__restrict__ node4, const TriRec *__restrict__ recs,
     const float *__restrict__ rays, const uint32_t *__restrict__ order, uint32_t rayNum,
     float *__restrict__ tOut, float *__restrict__ baryOut, uint32_t *__restrict__ primOut,
-    uint32_t *rayCounter, uint32_t *__restrict__ exactList, uint32_t *exactCount,
-    uint2 *__restrict__ spill, unsigned long long *counters, int REFILL_BELOW, int PARK_MIN, int STEP_MIN) {
+    uint32_t *rayCounter, const uint32_t *__restrict__ parents,
+    uint2 *__restrict__ spill, unsigned long long *counters) {
     // nodes waiting to be visited: node index + entry distance cut to its upper 16 bits (a lower
     // bound of a non-negative float, so the test on pop can only keep more)
     __shared__ uint32_t s_node[LDS_DEPTH * THREADS];
@@ -360,9 +413,10 @@ __global__ __launch_bounds__(THREADS) void closest_hit_accel_kernel(
     bool poolEmpty = false;
     uint32_t rayIdx = 0;
     RayState ray;
-    uint32_t offX = 0, offY = 32, offZ = 64; // byte offsets of the near planes inside a Node4
+    bool negX = false, negY = false, negZ = false; // which of min / max is the near plane
     uint32_t cur = 0;                        // node to visit next
-    bool needNode = false;                   // cur is used up: take the next node from the stack
+    bool needNode = false; // cur is used up: take the next node from the stack
+    uint32_t mode = MODE_FAST; // how hits of this ray are checked (see test_run)
     int sp = 0;
     uint32_t pendK0 = 0, pendC0 = 0, pendK1 = 0, pendC1 = 0;
     trav::Hit best;
@@ -383,21 +437,30 @@ __global__ __launch_bounds__(THREADS) void closest_hit_accel_kernel(
         // ---- retire finished rays, refill idle lanes ------------------------------------------------
         if (finished) {
             bool ok = true;
-            if (best.fi != 0xFFFFFFFFu)
+            if (best.fi != 0xFFFFFFFFu && mode == MODE_FAST)
                 ok = passes_parent(nodes, recs[best.k].parent, ray);
+            finished = false;
             if (ok) {
                 tOut[rayIdx] = best.t;
                 baryOut[2ull * rayIdx] = best.bx;
                 baryOut[2ull * rayIdx + 1] = best.by;
                 primOut[rayIdx] = best.fi;
-            } else
-                exactList[atomicAdd(exactCount, 1u)] = rayIdx;
-            if (COUNT) {
-                totNodes += nodeVisits;
-                totTris += triTests;
-                ++totRays;
+                if (COUNT) {
+                    totNodes += nodeVisits;
+                    totTris += triTests;
+                    ++totRays;
+                }
+            } else { // walk this ray again, checking every hit when it is taken
+                mode = MODE_CAREFUL;
+                best.t = FloatMax;
+                best.bx = best.by = 0.f;
+                best.fi = best.k = 0xFFFFFFFFu;
+                cur = 0;
+                sp = 0;
+                pendC0 = pendC1 = 0u;
+                needNode = false;
+                active = true;
             }
-            finished = false;
         }
         const unsigned long long idleMask = __ballot(!active);
         if (idleMask != 0ull && !poolEmpty) {
@@ -417,16 +480,24 @@ __global__ __launch_bounds__(THREADS) void closest_hit_accel_kernel(
                     ray.pos = {p[0], p[1], p[2]};
                     ray.dir = {p[3], p[4], p[5]};
                     ray.inv = 1.f / ray.dir;
-                    const bool regular =
-                        fabsf(ray.dir.x) > 1e-18f && fabsf(ray.dir.y) > 1e-18f &&
-                        fabsf(ray.dir.z) > 1e-18f && fabsf(ray.inv.x) < 1e18f &&
-                        fabsf(ray.inv.y) < 1e18f && fabsf(ray.inv.z) < 1e18f;
+                    const bool regular = fabsf(ray.inv.x) < 1e18f && fabsf(ray.inv.y) < 1e18f &&
+                                         fabsf(ray.inv.z) < 1e18f; // false for 0, denormal, NaN
+                    mode = MODE_FAST;
                     if (!regular) {
-                        exactList[atomicAdd(exactCount, 1u)] = rayIdx; // traced by the exact walker
-                    } else {
-                        offX = ray.dir.x < 0.f ? 16u : 0u;
-                        offY = ray.dir.y < 0.f ? 48u : 32u;
-                        offZ = ray.dir.z < 0.f ? 80u : 64u;
+                        // finite stand-ins keep the walk a superset of the reference's visits:
+                        // inside a slab -> (-huge, +huge), outside -> both the same sign
+                        mode = MODE_CHAIN;
+                        if (!(fabsf(ray.inv.x) < 1e18f))
+                            ray.inv.x = copysignf(1e18f, ray.dir.x);
+                        if (!(fabsf(ray.inv.y) < 1e18f))
+                            ray.inv.y = copysignf(1e18f, ray.dir.y);
+                        if (!(fabsf(ray.inv.z) < 1e18f))
+                            ray.inv.z = copysignf(1e18f, ray.dir.z);
+                    }
+                    {
+                        negX = ray.inv.x < 0.f;
+                        negY = ray.inv.y < 0.f;
+                        negZ = ray.inv.z < 0.f;
                         nodeVisits = triTests = 0;
                         best.t = FloatMax;
                         best.bx = best.by = 0.f;
@@ -479,41 +550,42 @@ __global__ __launch_bounds__(THREADS) void closest_hit_accel_kernel(
             // ---- (B) visit a node ------------------------------------------------------------------
             const bool canStep = active && !needNode && (pendC0 | pendC1) == 0u;
             if (canStep) {
-                // the record is 128-byte aligned: plane offsets go into the low address bits
-                const uint64_t base =
-                    reinterpret_cast<uint64_t>(node4Bytes) + (static_cast<uint64_t>(cur) << 7);
-                const uint32_t lo = static_cast<uint32_t>(base);
-                const uint64_t hi = base & 0xFFFFFFFF00000000ull;
-                const float4 nx = ld4(reinterpret_cast<const char *>(hi | (lo | offX)));
-                const float4 fx = ld4(reinterpret_cast<const char *>(hi | (lo | (offX ^ 16u))));
-                const float4 ny = ld4(reinterpret_cast<const char *>(hi | (lo | offY)));
-                const float4 fy = ld4(reinterpret_cast<const char *>(hi | (lo | (offY ^ 16u))));
-                const float4 nz = ld4(reinterpret_cast<const char *>(hi | (lo | offZ)));
-                const float4 fz = ld4(reinterpret_cast<const char *>(hi | (lo | (offZ ^ 16u))));
-                const uint4 ch = *reinterpret_cast<const uint4 *>(hi | (lo | 96u));
-                const uint4 cn = *reinterpret_cast<const uint4 *>(hi | (lo | 112u));
+                const uint4 *rec = reinterpret_cast<const uint4 *>(node4Bytes + (static_cast<size_t>(cur) << 6));
+                const uint4 w0 = rec[0], w1 = rec[1], w2 = rec[2], w3 = rec[3];
                 if (COUNT)
                     ++nodeVisits;
-                const float nxs[4] = {nx.x, nx.y, nx.z, nx.w}, fxs[4] = {fx.x, fx.y, fx.z, fx.w};
-                const float nys[4] = {ny.x, ny.y, ny.z, ny.w}, fys[4] = {fy.x, fy.y, fy.z, fy.w};
-                const float nzs[4] = {nz.x, nz.y, nz.z, nz.w}, fzs[4] = {fz.x, fz.y, fz.z, fz.w};
-                const uint32_t child[4] = {ch.x, ch.y, ch.z, ch.w};
-                const uint32_t cnt[4] = {cn.x, cn.y, cn.z, cn.w};
+                // plane distance = q * (2^exp / d) + (origin - o) / d
+                const float ax = ldexpf(ray.inv.x, static_cast<int>(static_cast<int8_t>(w0.w & 0xffu)));
+                const float ay = ldexpf(ray.inv.y, static_cast<int>(static_cast<int8_t>((w0.w >> 8) & 0xffu)));
+                const float az = ldexpf(ray.inv.z, static_cast<int>(static_cast<int8_t>((w0.w >> 16) & 0xffu)));
+                const float bx = (__uint_as_float(w0.x) - ray.pos.x) * ray.inv.x;
+                const float by = (__uint_as_float(w0.y) - ray.pos.y) * ray.inv.y;
+                const float bz = (__uint_as_float(w0.z) - ray.pos.z) * ray.inv.z;
+                // near / far plane bytes by the sign of the direction
+                const uint32_t qnx = negX ? w1.y : w1.x, qfx = negX ? w1.x : w1.y;
+                const uint32_t qny = negY ? w1.w : w1.z, qfy = negY ? w1.z : w1.w;
+                const uint32_t qnz = negZ ? w2.y : w2.x, qfz = negZ ? w2.x : w2.y;
+                const uint32_t child[4] = {w2.z, w2.w, w3.x, w3.y};
+                uint32_t cnt[4] = {w3.z & 0xffffu, w3.z >> 16, w3.w & 0xffffu, w3.w >> 16};
                 float key[4];
                 uint32_t leafCnt[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const float en = fmaxf(fmaxf(fmaxf((nxs[i] - ray.pos.x) * ray.inv.x,
-                                                       (nys[i] - ray.pos.y) * ray.inv.y),
-                                                 (nzs[i] - ray.pos.z) * ray.inv.z),
-                                           0.f);
-                    const float ex = fminf(fminf((fxs[i] - ray.pos.x) * ray.inv.x,
-                                                 (fys[i] - ray.pos.y) * ray.inv.y),
-                                           (fzs[i] - ray.pos.z) * ray.inv.z);
+                    const float hnx = __builtin_fmaf(static_cast<float>((qnx >> (8 * i)) & 0xffu), ax, bx);
+                    const float hny = __builtin_fmaf(static_cast<float>((qny >> (8 * i)) & 0xffu), ay, by);
+                    const float hnz = __builtin_fmaf(static_cast<float>((qnz >> (8 * i)) & 0xffu), az, bz);
+                    const float hfx = __builtin_fmaf(static_cast<float>((qfx >> (8 * i)) & 0xffu), ax, bx);
+                    const float hfy = __builtin_fmaf(static_cast<float>((qfy >> (8 * i)) & 0xffu), ay, by);
+                    const float hfz = __builtin_fmaf(static_cast<float>((qfz >> (8 * i)) & 0xffu), az, bz);
+                    const float en = fmaxf(fmaxf(fmaxf(hnx, hny), hnz), 0.f);
+                    const float ex = fminf(fminf(hfx, hfy), hfz);
                     // conservative: keep the slot unless the miss is beyond the rounding margin
-                    const bool hit = (en <= __builtin_fmaf(fabsf(ex), SLAB_REL, ex + SLAB_ABS)) &
-                                     (en <= limit);
+                    // (a NaN, possible only with overflowing stand-ins, keeps the slot)
+                    const bool hit = !(en > __builtin_fmaf(fabsf(ex), SLAB_REL, ex + SLAB_ABS)) &
+                                     !(en > limit) & (child[i] != EMPTY);
                     const bool isLeaf = cnt[i] != 0u;
+                    if (hit & (cnt[i] == CNT_LONG)) // a very long run: its length is in its first record
+                        cnt[i] = recs[child[i] & LEAF_MASK].run;
                     leafCnt[i] = (hit & isLeaf) ? cnt[i] : 0u;
                     key[i] = (hit & !isLeaf) ? en : __builtin_inff();
                 }
@@ -558,8 +630,8 @@ __global__ __launch_bounds__(THREADS) void closest_hit_accel_kernel(
             const int stepping = __popcll(__ballot(active && (pendC0 | pendC1) == 0u));
             if (parked != 0 && (parked >= PARK_MIN || stepping < STEP_MIN)) {
                 if ((pendC0 | pendC1) != 0u) {
-                    test_run<COUNT>(recs, ray, pendK0, pendC0, best, triTests);
-                    test_run<COUNT>(recs, ray, pendK1, pendC1, best, triTests);
+                    test_run<COUNT>(recs, nodes, parents, ray, mode, pendK0, pendC0, best, triTests);
+                    test_run<COUNT>(recs, nodes, parents, ray, mode, pendK1, pendC1, best, triTests);
                     pendC0 = pendC1 = 0u;
                 }
             }
@@ -584,15 +656,14 @@ __global__ __launch_bounds__(THREADS) void closest_hit_accel_kernel(
 }
 
 struct TraceWs {
-    size_t counter, spill, exactList, keysA, keysB, valsA, valsB, sortWs, sortWsBytes, total;
+    size_t counter, spill, keysA, keysB, valsA, valsB, sortWs, sortWsBytes, total;
 };
 inline TraceWs trace_ws(uint32_t rayNum) {
     TraceWs w;
     Carver c;
     const size_t n = rayNum ? rayNum : 1;
-    w.counter = c.take(256); // [0] ray queue head, [16] exact-list length, [32] exact queue head
+    w.counter = c.take(256); // [0] ray queue head
     w.spill = c.take(sizeof(uint2) * MAX_GRID * THREADS * (STACK_DEPTH - LDS_DEPTH));
-    w.exactList = c.take(4 * n);
     w.keysA = c.take(4 * n);
     w.keysB = c.take(4 * n);
     w.valsA = c.take(4 * n);
@@ -630,8 +701,8 @@ extern "C" int kk_trace_accel_build(const kk_lbvh_device_data *d_lbvh, const flo
                                                                         d_face_pos_idx, recs, face_num);
     KK_LAUNCH_CHECK();
     make_node4_kernel<<<div_up(nodeNum, THREADS), THREADS, 0, stream>>>(
-        d_lbvh, recs, reinterpret_cast<Node4 *>(b + l.nodes), reinterpret_cast<Header *>(b + l.header),
-        nodeNum);
+        d_lbvh, recs, reinterpret_cast<Node4 *>(b + l.nodes),
+        reinterpret_cast<uint32_t *>(b + l.parents), reinterpret_cast<Header *>(b + l.header), nodeNum);
     KK_LAUNCH_CHECK();
     return KK_OK;
 }
@@ -640,21 +711,19 @@ extern "C" size_t kk_closest_hit_accel_workspace_bytes(uint32_t ray_num) {
     return kk::accel::trace_ws(ray_num).total;
 }
 
-extern "C" int kk_closest_hit_accel(const void *d_accel, const kk_lbvh_device_data *d_lbvh,
-                                    const float *d_positions, const uint32_t *d_face_pos_idx,
-                                    uint32_t face_num, uint32_t compacted_face_num,
+extern "C" int kk_closest_hit_accel(const void *d_accel, uint32_t face_num,
+                                    uint32_t compacted_face_num,
                                     const float *d_rays, uint32_t ray_num, float *d_t, float *d_bary,
                                     uint32_t *d_prim, uint32_t flags,
                                     unsigned long long *d_counters, void *d_workspace,
                                     size_t workspace_bytes, void *stream_) {
     using namespace kk;
     using namespace kk::accel;
-    KK_REQUIRE(d_accel && d_lbvh && d_positions && d_face_pos_idx && d_rays && d_t && d_bary &&
-                   d_prim && d_workspace,
-               "null pointer");
+    KK_REQUIRE(d_accel && d_rays && d_t && d_bary && d_prim && d_workspace, "null pointer");
     KK_REQUIRE(face_num > 0 && compacted_face_num > 0 && compacted_face_num <= face_num,
                "tree sizes out of range");
-    KK_REQUIRE((flags & ~static_cast<uint32_t>(KK_TRACE_UNSORTED)) == 0, "unknown flag");
+    KK_REQUIRE((flags & ~static_cast<uint32_t>(KK_TRACE_UNSORTED | KK_TRACE_REUSE_ORDER)) == 0,
+               "unknown flag");
     if (ray_num == 0)
         return KK_OK;
     const TraceWs w = trace_ws(ray_num);
@@ -670,7 +739,9 @@ extern "C" int kk_closest_hit_accel(const void *d_accel, const kk_lbvh_device_da
     KK_HIP_TRY(hipMemsetAsync(rayCounter, 0, 256, stream));
 
     const uint32_t *order = nullptr;
-    if (!(flags & KK_TRACE_UNSORTED)) {
+    if (flags & KK_TRACE_REUSE_ORDER) {
+        order = reinterpret_cast<uint32_t *>(b + ((KEY_PASSES & 1) ? w.valsB : w.valsA));
+    } else if (!(flags & KK_TRACE_UNSORTED)) {
         auto *keysA = reinterpret_cast<uint32_t *>(b + w.keysA);
         auto *valsA = reinterpret_cast<uint32_t *>(b + w.valsA);
         auto *valsB = reinterpret_cast<uint32_t *>(b + w.valsB);
@@ -686,18 +757,15 @@ extern "C" int kk_closest_hit_accel(const void *d_accel, const kk_lbvh_device_da
     if (grid > MAX_GRID)
         grid = MAX_GRID;
     uint2 *spill = reinterpret_cast<uint2 *>(b + w.spill);
-    int tune[3] = {REFILL_BELOW_D, PARK_MIN_D, STEP_MIN_D};
-    if (const char *e = getenv("KK_TRACE_TUNE")) sscanf(e, "%d,%d,%d", &tune[0], &tune[1], &tune[2]);
-    uint32_t *exactList = reinterpret_cast<uint32_t *>(b + w.exactList);
+    const auto *parents = reinterpret_cast<const uint32_t *>(ab + l.parents);
     if (d_counters)
         closest_hit_accel_kernel<true><<<grid, THREADS, 0, stream>>>(
-            hdr, node4, recs, d_rays, order, ray_num, d_t, d_bary, d_prim, rayCounter, exactList,
-            rayCounter + 16, spill, d_counters, tune[0], tune[1], tune[2]);
+            hdr, node4, recs, d_rays, order, ray_num, d_t, d_bary, d_prim, rayCounter, parents,
+            spill, d_counters);
     else
         closest_hit_accel_kernel<false><<<grid, THREADS, 0, stream>>>(
-            hdr, node4, recs, d_rays, order, ray_num, d_t, d_bary, d_prim, rayCounter, exactList,
-            rayCounter + 16, spill, nullptr, tune[0], tune[1], tune[2]);
+            hdr, node4, recs, d_rays, order, ray_num, d_t, d_bary, d_prim, rayCounter, parents,
+            spill, nullptr);
     KK_LAUNCH_CHECK();
-    return trav::launch_listed(d_lbvh, d_positions, d_face_pos_idx, d_rays, d_t, d_bary, d_prim,
-                               rayCounter + 32, exactList, rayCounter + 16, stream);
+    return KK_OK;
 }

@@ -17,11 +17,7 @@ __global__ __launch_bounds__(THREADS) void closest_hit_kernel(
     const kk_lbvh_device_data *__restrict__ lbvh, const float *__restrict__ positions,
     const uint32_t *__restrict__ tri, const float *__restrict__ rays, uint32_t rayNum,
     float *__restrict__ tOut, float *__restrict__ baryOut, uint32_t *__restrict__ primOut,
-    uint32_t *rayCounter, unsigned long long *counters, const uint32_t *__restrict__ list,
-    const uint32_t *__restrict__ listCount) {
-    // with a list, the rays to trace are list[0 .. *listCount)
-    if (list)
-        rayNum = *listCount;
+    uint32_t *rayCounter, unsigned long long *counters) {
     __shared__ uint32_t s_stack[STACK_DEPTH * THREADS];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -60,8 +56,8 @@ __global__ __launch_bounds__(THREADS) void closest_hit_kernel(
             if (!active) {
                 const uint32_t r = base + __popcll(idleMask & lanesBelow);
                 if (r < rayNum && r >= base) {
-                    rayIdx = list ? list[r] : r;
-                    const float *p = rays + 6ull * rayIdx;
+                    rayIdx = r;
+                    const float *p = rays + 6ull * r;
                     ray.pos = {p[0], p[1], p[2]};
                     ray.dir = {p[3], p[4], p[5]};
                     nodeFetches = triTests = 0;
@@ -115,22 +111,6 @@ __global__ __launch_bounds__(THREADS) void closest_hit_kernel(
 } // namespace trav
 } // namespace kk
 
-namespace kk {
-namespace trav {
-// Traces rays[list[i]], i < *listCount, with the exact walk (a small launch: the list holds the few
-// rays the fast kernel hands back). rayCounter must be zero.
-int launch_listed(const kk_lbvh_device_data *lbvh, const float *positions, const uint32_t *tri,
-                  const float *rays, float *tOut, float *baryOut, uint32_t *primOut,
-                  uint32_t *rayCounter, const uint32_t *list, const uint32_t *listCount,
-                  hipStream_t stream) {
-    closest_hit_kernel<false><<<64, THREADS, 0, stream>>>(lbvh, positions, tri, rays, 0u, tOut, baryOut,
-                                                          primOut, rayCounter, nullptr, list, listCount);
-    KK_LAUNCH_CHECK();
-    return KK_OK;
-}
-} // namespace trav
-} // namespace kk
-
 extern "C" size_t kk_closest_hit_workspace_bytes(void) { return 256; }
 
 extern "C" int kk_closest_hit(const kk_lbvh_device_data *d_lbvh, const float *d_positions,
@@ -157,13 +137,11 @@ extern "C" int kk_closest_hit(const kk_lbvh_device_data *d_lbvh, const float *d_
     if (d_counters)
         closest_hit_kernel<true><<<grid, THREADS, 0, stream>>>(d_lbvh, d_positions, d_face_pos_idx,
                                                                d_rays, ray_num, d_t, d_bary, d_prim,
-                                                               rayCounter, d_counters, nullptr,
-                                                               nullptr);
+                                                               rayCounter, d_counters);
     else
         closest_hit_kernel<false><<<grid, THREADS, 0, stream>>>(d_lbvh, d_positions, d_face_pos_idx,
                                                                 d_rays, ray_num, d_t, d_bary, d_prim,
-                                                                rayCounter, nullptr, nullptr,
-                                                                nullptr);
+                                                                rayCounter, nullptr);
     KK_LAUNCH_CHECK();
     return KK_OK;
 }

@@ -31,3 +31,9 @@ for sort in (False, True):
     same_p = bool((got[2] == ref[2]).all()); same_t = bool((got[0] == ref[0]).all()); same_b = bool((got[1] == ref[1]).all())
     print(f"trace-layout sort={sort}: {ms:.3f} ms  {R/ms/1e3:.1f} Mrays/s  prim_eq={same_p} t_eq={same_t} bary_eq={same_b}",
           {k: (round(v / R, 2) if k != 'dbg' else v) for k, v in got[3].items()}, flush=True)
+from raytracer_amd import _lib
+l = _lib.lib()
+ws = torch.zeros(l.kk_closest_hit_accel_workspace_bytes(R), dtype=torch.uint8, device=dev)
+t = torch.empty(R, dtype=torch.float32, device=dev); b = torch.empty((R, 2), dtype=torch.float32, device=dev); pr = torch.empty(R, dtype=torch.int32, device=dev)
+closest_hit(bvh, rays, out=(t, b, pr, ws)); torch.cuda.synchronize()
+print("exact-list length:", int(ws[:256].view(torch.int32)[16]), "queue heads:", ws[:256].view(torch.int32)[[0, 32]].tolist())

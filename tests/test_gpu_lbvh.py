@@ -177,8 +177,11 @@ def test_full_size_build_properties():
     assert bool((fb[sel][:, :3] <= child[:, :3]).all()) and bool((fb[sel][:, 3:] >= child[:, 3:]).all())
 
 
-def _compare_hits(oracle, bvh, ref, pos, tri, rays):
-    t, bary, prim, cnt = closest_hit(bvh, rays, count=True)
+LAYOUTS = [("build", True), ("trace", True), ("trace", False)]
+
+
+def _compare_hits(oracle, bvh, ref, pos, tri, rays, layout="trace", sort=True):
+    t, bary, prim, cnt = closest_hit(bvh, rays, count=True, layout=layout, sort=sort)
     torch.cuda.synchronize()
     t, bary, prim = t.cpu().numpy(), bary.cpu().numpy(), prim.cpu().numpy().view(np.uint32)
     rt, rbary, rprim, rstats = oracle.closest_hit(ref, pos, tri, rays)
@@ -198,12 +201,36 @@ def _compare_hits(oracle, bvh, ref, pos, tri, rays):
     return frac, int(hit.sum())
 
 
-def test_closest_hit_soup(oracle):
+@pytest.mark.parametrize("layout,sort", LAYOUTS)
+def test_closest_hit_soup(oracle, layout, sort):
     pos, tri = syn.triangle_soup(100_000)
     rays = syn.incoherent_rays(65_536)
     bvh, ref = _compare_build(oracle, pos, tri)
-    frac, hits = _compare_hits(oracle, bvh, ref, pos, tri, rays)
+    frac, hits = _compare_hits(oracle, bvh, ref, pos, tri, rays, layout, sort)
     assert hits > 10_000
+
+
+def test_closest_hit_layouts_agree_bitwise():
+    """The repacked tree and the build's own tree give the same bits for every ray, zero direction
+    components, rays from outside the scene and duplicate-Morton leaves included."""
+    pos, tri = syn.triangle_soup(300_000, half_extent=0.02)
+    # squeeze a tenth of the triangles into one Morton cell so that long leaf runs exist
+    pos = pos.copy().reshape(-1, 3, 3)
+    pos[::10] = pos[::10] * np.float32(1e-4) + np.float32(0.5)
+    pos = pos.reshape(-1, 3)
+    bvh = LBVH(DEV)
+    bvh.BuildFrom(pos, tri)
+    rays = syn.incoherent_rays(200_000)
+    rays[:50_000, :3] = rays[:50_000, :3] * 3 - 1          # origins outside the unit box
+    rays[1000:1300, 3:] = np.array([0, 0, -1], np.float32)  # axis-parallel
+    rays[1300:1600, 3:] = np.array([0.6, 0, 0.8], np.float32)
+    rays[1600:1900, :3] = np.float32(0.5)                   # inside the dense cell
+    ref = [x.cpu().numpy() for x in closest_hit(bvh, rays, layout="build")]
+    for srt in (True, False):
+        got = [x.cpu().numpy() for x in closest_hit(bvh, rays, layout="trace", sort=srt)]
+        for a, b in zip(ref, got):
+            assert a.tobytes() == b.tobytes()
+    assert (ref[2] >= 0).mean() > 0.5
 
 
 def test_closest_hit_veach_mis(oracle, veach):
@@ -220,8 +247,9 @@ def test_closest_hit_veach_mis(oracle, veach):
     extra = np.array([[0, 10, 0, 0, -1, 0], [0, 3, 0, 1, 0, 0], [1, 3, 1, 0, 0, -1],
                       [0, 10, 0, 0, 1, 0]], np.float32)
     rays = np.concatenate([rays, extra])
-    frac, hits = _compare_hits(oracle, bvh, ref, pos, tri, rays)
-    assert hits > 5_000
+    for layout, srt in LAYOUTS:
+        frac, hits = _compare_hits(oracle, bvh, ref, pos, tri, rays, layout, srt)
+        assert hits > 5_000
 
 
 def test_closest_hit_single_leaf(oracle):
@@ -230,6 +258,7 @@ def test_closest_hit_single_leaf(oracle):
     bvh = LBVH(DEV)
     bvh.BuildFrom(pos, tri)
     rays = np.array([[0.2, 0.2, 1, 0, 0, -1], [2, 2, 1, 0, 0, -1]], np.float32)
-    t, bary, prim = closest_hit(bvh, rays)
-    assert prim.cpu().numpy().tolist() == [0, -1]
-    assert float(t[0]) == 1.0
+    for layout in ("build", "trace"):
+        t, bary, prim = closest_hit(bvh, rays, layout=layout)
+        assert prim.cpu().numpy().tolist() == [0, -1]
+        assert float(t[0]) == 1.0
