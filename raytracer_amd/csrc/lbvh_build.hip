@@ -27,7 +27,6 @@ namespace lbvh {
 
 constexpr int THREADS = 256;
 constexpr uint32_t LEAF = 0x80000000u;
-constexpr uint32_t LEAF_MASK = 0x7fffffffu;
 constexpr int BOUNDS_MAX_BLOCKS = 2048;
 constexpr int HEADS_PER_THREAD = 4;
 constexpr int HEADS_PER_BLOCK = THREADS * HEADS_PER_THREAD;
@@ -395,22 +394,27 @@ __device__ __forceinline__ AABB load_box(const float *p) {
     return b;
 }
 
-// Bottom-up box refit in two kernels. Every internal node has an arrival counter: the first child to
-// arrive stops, the second one unions both children's boxes and climbs on.
-//   refit_local : one workgroup owns REFIT_LEAVES consecutive leaves (consecutive in Morton order, so
-//                 almost every subtree above them lies inside the group). While a parent's leaf range
-//                 lies inside the group's leaves, its counter and the boxes of the group's internal
-//                 nodes live in LDS (a node's index is an end of its range, so it falls inside the
-//                 group's window too); only finished boxes go to memory, with plain stores and no
-//                 fence. A thread whose parent straddles a group boundary appends its child to a work
-//                 list and stops.
-//   refit_top   : the listed children (about 1 % of the nodes, the top of the tree) climb on with
-//                 global counters. A counter is an acquire-release agent-scope atomic: the arriving
-//                 thread wrote its child's box itself (or an earlier kernel did), the release publishes
-//                 it, and the second arrival's acquire makes the sibling's box visible.
+// Internal-node boxes without a bottom-up dependency chain.
+//
+// The reference gives node i the union of everything in its leaf range [lo, hi], folded in leaf order
+// with "replace only if strictly smaller / larger" (bounding_box.h:24-41 through lbvh.cu:286-310), so a
+// coordinate of the result is the LEFTMOST extreme element of the range (this matters for -0 / +0
+// only). Any way of combining in-order pieces that keeps the left operand on a tie gives the same
+// bits, so the box of a node is a range query over the leaf boxes:
+//   refit_window : one workgroup per REFIT_LEAVES consecutive leaves builds, component by component, a
+//                  sparse table in LDS (level k holds the fold of 2^k leaves) and answers every node
+//                  whose range lies inside the window with two overlapping table entries. It also
+//                  writes the fold of every aligned 32-leaf block and of the whole window.
+//   block_totals : folds of aligned blocks of 32^3, 32^4, ... leaves (a few thousand values).
+//   refit_span   : a node whose range crosses a window boundary walks its range left to right in the
+//                  largest aligned blocks that fit (at most 31 per level and side).
 constexpr int REFIT_LPT = 4;
-constexpr int REFIT_LEAVES = THREADS * REFIT_LPT;
-constexpr int REFIT_TOP_BLOCKS = 1024;
+constexpr int REFIT_LEAVES = THREADS * REFIT_LPT; // 1024 = 32^2
+constexpr int REFIT_LOG = 10;
+constexpr int RADIX_LOG = 5; // aligned block totals exist for 32^l leaves, l = 1, 2, ...
+constexpr int MAX_TOTAL_LEVELS = 7;
+constexpr int REFIT_SPAN_BLOCKS = 1024;
+static_assert(REFIT_LEAVES == (1 << REFIT_LOG) && REFIT_LOG == 2 * RADIX_LOG, "window = 32^2 leaves");
 
 __device__ __forceinline__ void store_box(float *p, const AABB &b) {
     p[0] = b.minPos.x;
@@ -421,24 +425,54 @@ __device__ __forceinline__ void store_box(float *p, const AABB &b) {
     p[5] = b.maxPos.z;
 }
 
-__global__ __launch_bounds__(THREADS) void refit_local_kernel(
+// Where the totals of each level start (in boxes) inside the totals array; level l has
+// ceil(capacity / 32^l) entries. Level 0 is the leaf boxes themselves and is not stored here.
+struct TotalsLayout {
+    uint32_t levels;                      // highest level stored
+    uint64_t start[MAX_TOTAL_LEVELS + 1]; // start[l], l = 1 .. levels
+    uint64_t boxes;
+};
+inline TotalsLayout totals_layout(uint32_t capacity) {
+    TotalsLayout t{};
+    uint64_t off = 0;
+    uint32_t l = 1;
+    for (;; ++l) {
+        const uint64_t unit = 1ull << (RADIX_LOG * l);
+        t.start[l] = off;
+        off += (capacity + unit - 1) / unit;
+        if (unit >= capacity || l == MAX_TOTAL_LEVELS)
+            break;
+    }
+    t.levels = l;
+    t.boxes = off;
+    return t;
+}
+
+// keeps the left operand on a tie, like AABB::Expand
+__device__ __forceinline__ float fold_min(float a, float b) { return (a > b) ? b : a; }
+__device__ __forceinline__ float fold_max(float a, float b) { return (a < b) ? b : a; }
+
+// start of level k (1 .. REFIT_LOG) in the compact table: level j holds REFIT_LEAVES + 1 - 2^j entries
+__host__ __device__ constexpr int tab_off(int k) { return (k - 1) * (REFIT_LEAVES + 1) - ((1 << k) - 2); }
+constexpr int TAB_ENTRIES = tab_off(REFIT_LOG + 1);
+
+__global__ __launch_bounds__(REFIT_LEAVES) void refit_window_kernel(
     const float *__restrict__ leafAABBs, const kk_lbvh_device_data *__restrict__ hdr,
-    kk_lbvh_node *nodes, const uint32_t *__restrict__ nodeParents,
-    const uint32_t *__restrict__ leafParents, const uint32_t *__restrict__ rangeEnds,
-    uint32_t *__restrict__ topList, uint32_t *topCount) {
-    __shared__ uint32_t s_cnt[REFIT_LEAVES];
-    __shared__ float s_box[REFIT_LEAVES][6];
+    kk_lbvh_node *nodes, const uint32_t *__restrict__ rangeEnds, float *__restrict__ totals,
+    TotalsLayout tl, uint32_t *__restrict__ topList, uint32_t *topCount) {
+    // one thread per leaf / node; the table is built for one axis at a time, (min, max) together,
+    // two levels per barrier
+    __shared__ float2 s_l0[REFIT_LEAVES]; // level 0 of the current axis
+    __shared__ float2 s_tab[TAB_ENTRIES]; // s_tab[tab_off(k) + j] = fold of leaves [j, j + 2^k)
     const uint32_t M = hdr->compacted_face_num;
     const uint32_t b0 = blockIdx.x * REFIT_LEAVES;
     if (b0 >= M)
         return;
     const uint32_t b1 = (b0 + REFIT_LEAVES < M) ? b0 + REFIT_LEAVES : M; // leaves [b0, b1)
-    for (int i = threadIdx.x; i < REFIT_LEAVES; i += THREADS)
-        s_cnt[i] = 0;
-    __syncthreads();
+    const int tid = threadIdx.x;
     if (M == 1) {
         // No internal node exists; give traversal a root whose two children are the only leaf.
-        if (threadIdx.x == 0) {
+        if (tid == 0) {
             nodes[0].lft = LEAF;
             nodes[0].rht = LEAF;
             for (int k = 0; k < 3; ++k) {
@@ -448,74 +482,142 @@ __global__ __launch_bounds__(THREADS) void refit_local_kernel(
         }
         return;
     }
-    for (int j = 0; j < REFIT_LPT; ++j) {
-        const uint32_t c = b0 + j * THREADS + threadIdx.x;
-        if (c >= b1)
-            continue;
-        AABB box = load_box(leafAABBs + 6ull * c);
-        uint32_t child = c | LEAF;
-        uint32_t node = leafParents[c];
-        for (int guard = 0; guard < 64; ++guard) {
-            const uint32_t other = rangeEnds[node];
-            const uint32_t lo = node < other ? node : other, hi = node < other ? other : node;
-            if (!(lo >= b0 && hi < b1)) {
-                topList[atomicAdd(topCount, 1u)] = child;
-                break;
+    // this thread's leaf (the fold's identity past the last one) and node
+    const uint32_t i = b0 + tid;
+    AABB mine = i < b1 ? load_box(leafAABBs + 6ull * i) : AABB::Initial();
+    const bool exists = i < b1 && i < M - 1;
+    uint32_t qlo = 0, qhi = 0;
+    bool inside = false;
+    if (exists) {
+        const uint32_t other = rangeEnds[i];
+        const uint32_t lo = i < other ? i : other, hi = i < other ? other : i;
+        inside = lo >= b0 && hi < b1;
+        qlo = lo - b0;
+        qhi = hi - b0;
+    }
+    const int qk = inside ? 31 - __clz(static_cast<int>(qhi - qlo + 1)) : 1; // range length >= 2
+    float2 res[3];
+    const bool fullWindow = b1 - b0 == REFIT_LEAVES; // totals of a partial block are never used
+    auto comb = [](float2 a, float2 b) { return make_float2(fold_min(a.x, b.x), fold_max(a.y, b.y)); };
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {
+        s_l0[tid] = make_float2(mine.minPos[ax], mine.maxPos[ax]);
+        __syncthreads();
+#pragma unroll
+        for (int k = 1; k <= REFIT_LOG; k += 2) { // levels k and k + 1 from level k - 1
+            const float2 *prev = k == 1 ? s_l0 : s_tab + tab_off(k - 1);
+            const int h = 1 << (k - 1);
+            if (tid + 2 * h <= REFIT_LEAVES) {
+                const float2 lo2 = comb(prev[tid], prev[tid + h]);
+                s_tab[tab_off(k) + tid] = lo2;
+                if (tid + 4 * h <= REFIT_LEAVES)
+                    s_tab[tab_off(k + 1) + tid] = comb(lo2, comb(prev[tid + 2 * h], prev[tid + 3 * h]));
             }
-            const uint32_t lft = nodes[node].lft, rht = nodes[node].rht;
-            const uint32_t up = nodeParents[node];
-            const uint32_t sibling = (lft == child) ? rht : lft;
-            // LDS only: the box written below and this counter are both LDS accesses of one wave and
-            // are performed in order, so a workgroup-scope fence over LDS is all the ordering needed.
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-            const uint32_t old = __hip_atomic_fetch_add(&s_cnt[node - b0], 1u, __ATOMIC_RELAXED,
-                                                        __HIP_MEMORY_SCOPE_WORKGROUP);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-            if (old == 0)
-                break;
-            box.Expand((sibling & LEAF) ? load_box(leafAABBs + 6ull * (sibling & LEAF_MASK))
-                                        : load_box(s_box[sibling - b0]));
-            store_box(s_box[node - b0], box);
-            store_box(nodes[node].aabb_min, box);
-            if (node == 0)
-                break;
-            child = node;
-            node = up;
+            __syncthreads();
         }
+        if (inside)
+            res[ax] = comb(s_tab[tab_off(qk) + qlo], s_tab[tab_off(qk) + qhi + 1 - (1u << qk)]);
+        // aligned block totals: 32 blocks of 32 leaves and the window itself
+        if (tid < 32 && (b0 + (tid + 1) * 32 <= M)) {
+            const float2 v = s_tab[tab_off(RADIX_LOG) + tid * 32];
+            float *o = totals + 6 * (tl.start[1] + (b0 >> RADIX_LOG) + tid);
+            o[ax] = v.x;
+            o[3 + ax] = v.y;
+        }
+        if (tid == 32 && fullWindow) {
+            const float2 v = s_tab[tab_off(REFIT_LOG)];
+            float *o = totals + 6 * (tl.start[2] + (b0 >> REFIT_LOG));
+            o[ax] = v.x;
+            o[3 + ax] = v.y;
+        }
+        __syncthreads();
+    }
+    // nodes that cross the window's boundary go to the work list: one global atomic per workgroup
+    __shared__ uint32_t s_listed, s_listBase;
+    if (tid == 0)
+        s_listed = 0;
+    __syncthreads();
+    uint32_t slot = 0;
+    if (exists && !inside)
+        slot = atomicAdd(&s_listed, 1u);
+    __syncthreads();
+    if (tid == 0 && s_listed != 0)
+        s_listBase = atomicAdd(topCount, s_listed);
+    __syncthreads();
+    if (exists) {
+        if (inside) {
+            float *o = nodes[i].aabb_min;
+            o[0] = res[0].x, o[1] = res[1].x, o[2] = res[2].x;
+            o[3] = res[0].y, o[4] = res[1].y, o[5] = res[2].y;
+        } else
+            topList[s_listBase + slot] = i;
     }
 }
 
-__global__ __launch_bounds__(THREADS) void refit_top_kernel(
-    const float *__restrict__ leafAABBs, kk_lbvh_node *nodes,
-    const uint32_t *__restrict__ nodeParents, const uint32_t *__restrict__ leafParents,
-    const uint32_t *__restrict__ topList, const uint32_t *__restrict__ topCount,
-    uint32_t *arrivals) {
+// Totals of aligned blocks of 32^l leaves, l >= 3, each the in-order fold of its 32 children of
+// level l - 1. One workgroup: the levels above a window hold a few thousand entries in all.
+__global__ __launch_bounds__(1024) void block_totals_kernel(
+    const kk_lbvh_device_data *__restrict__ hdr, float *totals, TotalsLayout tl) {
+    const uint32_t M = hdr->compacted_face_num;
+    for (uint32_t l = 3; l <= tl.levels; ++l) {
+        const uint64_t unit = 1ull << (RADIX_LOG * l);
+        const uint32_t full = static_cast<uint32_t>(M / unit); // only whole blocks are ever used
+        for (uint32_t b = threadIdx.x; b < full; b += blockDim.x) {
+            AABB acc = AABB::Initial();
+            const float *src = totals + 6 * (tl.start[l - 1] + 32ull * b);
+            for (int j = 0; j < 32; ++j)
+                acc.Expand(load_box(src + 6 * j));
+            store_box(totals + 6 * (tl.start[l] + b), acc);
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(THREADS) void refit_span_kernel(
+    const float *__restrict__ leafAABBs, const kk_lbvh_device_data *__restrict__ hdr,
+    kk_lbvh_node *nodes, const uint32_t *__restrict__ rangeEnds, const float *__restrict__ totals,
+    TotalsLayout tl, const uint32_t *__restrict__ topList, const uint32_t *__restrict__ topCount) {
     const uint32_t count = *topCount;
     for (uint32_t e = blockIdx.x * THREADS + threadIdx.x; e < count; e += gridDim.x * THREADS) {
-        uint32_t child = topList[e];
-        uint32_t node = (child & LEAF) ? leafParents[child & LEAF_MASK] : nodeParents[child];
-        for (int guard = 0; guard < 64; ++guard) {
-            const uint32_t old = __hip_atomic_fetch_add(&arrivals[node], 1u, __ATOMIC_ACQ_REL,
-                                                        __HIP_MEMORY_SCOPE_AGENT);
-            if (old == 0)
+        const uint32_t i = topList[e];
+        const uint32_t other = rangeEnds[i];
+        uint64_t p = i < other ? i : other;                 // next leaf to take in
+        const uint64_t end = (i < other ? other : i) + 1ull; // one past the range
+        AABB acc = AABB::Initial();
+        // climb: single leaves up to a multiple of 32, blocks of 32 up to a multiple of 1024, ...
+        uint32_t l = 0;
+        while (true) {
+            const uint64_t unit = 1ull << (RADIX_LOG * l), next = unit << RADIX_LOG;
+            const float *src = l == 0 ? leafAABBs : totals + 6 * tl.start[l];
+            while ((p & (next - 1)) != 0 && p + unit <= end) {
+                acc.Expand(load_box(src + 6 * (p >> (RADIX_LOG * l))));
+                p += unit;
+            }
+            if (l < tl.levels && (p & (next - 1)) == 0 && p + next <= end)
+                ++l;
+            else
                 break;
-            const uint32_t lft = nodes[node].lft, rht = nodes[node].rht;
-            AABB box = (lft & LEAF) ? load_box(leafAABBs + 6ull * (lft & LEAF_MASK))
-                                    : load_box(nodes[lft].aabb_min);
-            box.Expand((rht & LEAF) ? load_box(leafAABBs + 6ull * (rht & LEAF_MASK))
-                                    : load_box(nodes[rht].aabb_min));
-            store_box(nodes[node].aabb_min, box);
-            if (node == 0)
-                break;
-            child = node;
-            node = nodeParents[node];
         }
+        // descend: as many blocks of the current size as still fit, then smaller ones
+        while (true) {
+            const uint64_t unit = 1ull << (RADIX_LOG * l);
+            const float *src = l == 0 ? leafAABBs : totals + 6 * tl.start[l];
+            while (p + unit <= end) {
+                acc.Expand(load_box(src + 6 * (p >> (RADIX_LOG * l))));
+                p += unit;
+            }
+            if (l == 0)
+                break;
+            --l;
+        }
+        store_box(nodes[i].aabb_min, acc);
     }
 }
 
 struct Ws {
     kk_lbvh_ws_layout pub;
-    size_t params, partials, keys1, vals1, blockCounts, arrivals, rangeEnds, topList, sortWs;
+    size_t params, partials, keys1, vals1, blockCounts, topCount, rangeEnds, topList, totals, sortWs;
     size_t sortWsBytes;
     uint32_t headBlocks;
 };
@@ -536,9 +638,10 @@ inline Ws layout(uint32_t N, uint32_t flags) {
     w.pub.node_parents = c.take(4 * n);
     w.pub.leaf_parents = c.take(4 * n);
     w.blockCounts = c.take(4 * static_cast<size_t>(w.headBlocks));
-    w.arrivals = c.take(4 * n + 4);
+    w.topCount = c.take(4);
     w.rangeEnds = c.take(4 * n);
     w.topList = c.take(4 * n);
+    w.totals = c.take(24 * totals_layout(N).boxes);
     w.sortWsBytes = kk_sort_workspace_bytes(N);
     w.sortWs = c.take(w.sortWsBytes);
     // the sort's error word sits right after its histogram and counters (radix_sort.hip: sort_ws)
@@ -588,7 +691,8 @@ extern "C" int kk_lbvh_build(const float *d_positions, uint32_t vert_num,
     auto *nodeParents = reinterpret_cast<uint32_t *>(b + w.pub.node_parents);
     auto *leafParents = reinterpret_cast<uint32_t *>(b + w.pub.leaf_parents);
     auto *blockCounts = reinterpret_cast<uint32_t *>(b + w.blockCounts);
-    auto *arrivals = reinterpret_cast<uint32_t *>(b + w.arrivals);
+    auto *topCount = reinterpret_cast<uint32_t *>(b + w.topCount);
+    auto *totals = reinterpret_cast<float *>(b + w.totals);
     auto *rangeEnds = reinterpret_cast<uint32_t *>(b + w.rangeEnds);
     auto *topList = reinterpret_cast<uint32_t *>(b + w.topList);
     const uint32_t N = face_num;
@@ -629,15 +733,17 @@ extern "C" int kk_lbvh_build(const float *d_positions, uint32_t vert_num,
     karras_links_kernel<<<ngrid, THREADS, 0, stream>>>(uniq, d_out, d_nodes, nodeParents,
                                                        leafParents, rangeEnds);
     KK_LAUNCH_CHECK();
-    // arrivals[0 .. N) are the top-phase counters; the word after them counts the work list
-    KK_HIP_TRY(hipMemsetAsync(arrivals, 0, 4ull * N + 4, stream));
-    uint32_t *topCount = arrivals + N;
-    refit_local_kernel<<<div_up(N, REFIT_LEAVES), THREADS, 0, stream>>>(
-        leafAABBs, d_out, d_nodes, nodeParents, leafParents, rangeEnds, topList, topCount);
+    KK_HIP_TRY(hipMemsetAsync(topCount, 0, 4, stream));
+    const TotalsLayout tl = totals_layout(N);
+    refit_window_kernel<<<div_up(N, REFIT_LEAVES), REFIT_LEAVES, 0, stream>>>(
+        leafAABBs, d_out, d_nodes, rangeEnds, totals, tl, topList, topCount);
     KK_LAUNCH_CHECK();
-    refit_top_kernel<<<REFIT_TOP_BLOCKS, THREADS, 0, stream>>>(leafAABBs, d_nodes, nodeParents,
-                                                               leafParents, topList, topCount,
-                                                               arrivals);
+    if (tl.levels >= 3) {
+        block_totals_kernel<<<1, 1024, 0, stream>>>(d_out, totals, tl);
+        KK_LAUNCH_CHECK();
+    }
+    refit_span_kernel<<<REFIT_SPAN_BLOCKS, THREADS, 0, stream>>>(leafAABBs, d_out, d_nodes, rangeEnds,
+                                                                 totals, tl, topList, topCount);
     KK_LAUNCH_CHECK();
     return KK_OK;
 }
