@@ -83,8 +83,8 @@ typedef struct kk_lbvh_ws_layout {
     size_t unsorted_mortons; /* uint32[N]  only with KK_LBVH_KEEP_STAGES (lbvh.cu:136-170) */
     size_t unique_mortons;   /* uint32[M]  one code per leaf (lbvh.cu:202) */
     size_t leaf_aabbs;       /* float[M][6] per-leaf boxes (lbvh.cu:204-216) */
-    size_t node_parents;     /* uint32[M-1] parent of each internal node (node 0: 0xFFFFFFFF) */
-    size_t leaf_parents;     /* uint32[M]  parent of each leaf */
+    size_t node_parents;     /* uint32[M-1] parent of each internal node (node 0: 0xFFFFFFFF); KEEP_STAGES only */
+    size_t leaf_parents;     /* uint32[M]  parent of each leaf; KEEP_STAGES only */
     size_t error_flag;       /* uint32     non-zero if a sort look-back gave up */
 } kk_lbvh_ws_layout;
 

@@ -152,13 +152,28 @@ __device__ __forceinline__ uint32_t expand10BitsTo32(uint32_t v) {
 __device__ __forceinline__ f3 load3(const float *__restrict__ p, uint32_t i) {
     return {p[3ull * i], p[3ull * i + 1], p[3ull * i + 2]};
 }
+__device__ __forceinline__ AABB load_box(const float *p) {
+    AABB b;
+    b.minPos = {p[0], p[1], p[2]};
+    b.maxPos = {p[3], p[4], p[5]};
+    return b;
+}
+__device__ __forceinline__ void store_box(float *p, const AABB &b) {
+    p[0] = b.minPos.x;
+    p[1] = b.minPos.y;
+    p[2] = b.minPos.z;
+    p[3] = b.maxPos.x;
+    p[4] = b.maxPos.y;
+    p[5] = b.maxPos.z;
+}
 
 // lbvh.cu:136-170, one thread per face.
 __global__ __launch_bounds__(THREADS) void morton_kernel(const float *__restrict__ pos,
                                                          const uint32_t *__restrict__ tri,
                                                          uint32_t faceNum,
                                                          const BuildParams *__restrict__ params,
-                                                         uint32_t *__restrict__ mortons) {
+                                                         uint32_t *__restrict__ mortons,
+                                                         float *__restrict__ faceBoxes) {
     const uint32_t fi = blockIdx.x * THREADS + threadIdx.x;
     if (fi >= faceNum)
         return;
@@ -168,6 +183,9 @@ __global__ __launch_bounds__(THREADS) void morton_kernel(const float *__restrict
     box.Expand(load3(pos, tri[3ull * fi]));
     box.Expand(load3(pos, tri[3ull * fi + 1]));
     box.Expand(load3(pos, tri[3ull * fi + 2]));
+    // kept for the leaf boxes: gathering one 24-byte box per sorted face later costs a third of the
+    // lines that gathering its indices and vertices again would
+    store_box(faceBoxes + 6ull * fi, box);
     f3 c = .5f * (box.minPos + box.maxPos);
     c = (c - minPos) * invDlt;
     c.x = gmin(gmax(c.x * 1024.f, 0.f), 1023.f);
@@ -285,11 +303,12 @@ __global__ __launch_bounds__(THREADS) void compact_heads_kernel(
         }
 }
 
-// lbvh.cu:186-219, one thread per leaf (run of equal codes).
+// lbvh.cu:186-219, one thread per leaf (run of equal codes): the in-order fold of its faces' boxes,
+// which is the in-order fold of their vertices.
 __global__ __launch_bounds__(THREADS) void leaf_aabb_kernel(
-    const float *__restrict__ pos, const uint32_t *__restrict__ tri,
-    const uint32_t *__restrict__ faces, const uint32_t *__restrict__ compacted,
-    const kk_lbvh_device_data *__restrict__ hdr, float *__restrict__ leafAABBs) {
+    const float *__restrict__ faceBoxes, const uint32_t *__restrict__ faces,
+    const uint32_t *__restrict__ compacted, const kk_lbvh_device_data *__restrict__ hdr,
+    float *__restrict__ leafAABBs) {
     const uint32_t M = hdr->compacted_face_num;
     const uint32_t N = hdr->face_num;
     const uint32_t c = blockIdx.x * THREADS + threadIdx.x;
@@ -298,38 +317,51 @@ __global__ __launch_bounds__(THREADS) void leaf_aabb_kernel(
     const uint32_t beg = compacted[c];
     const uint32_t end = (c == M - 1) ? N : compacted[c + 1];
     AABB box = AABB::Initial();
-    for (uint32_t k = beg; k < end; ++k) {
-        const uint32_t face = faces[k];
-        box.Expand(load3(pos, tri[3ull * face]));
-        box.Expand(load3(pos, tri[3ull * face + 1]));
-        box.Expand(load3(pos, tri[3ull * face + 2]));
-    }
-    float *o = leafAABBs + 6ull * c;
-    o[0] = box.minPos.x;
-    o[1] = box.minPos.y;
-    o[2] = box.minPos.z;
-    o[3] = box.maxPos.x;
-    o[4] = box.maxPos.y;
-    o[5] = box.maxPos.z;
+    for (uint32_t k = beg; k < end; ++k)
+        box.Expand(load_box(faceBoxes + 6ull * faces[k]));
+    store_box(leafAABBs + 6ull * c, box);
 }
 
 // lbvh.cu:221-232: length of the common leading-zero run of code[i] ^ code[j], -1 out of range.
-__device__ __forceinline__ int delta(const uint32_t *__restrict__ m, uint32_t mi, int64_t j,
-                                     int64_t inodeNum) {
+// Codes near the workgroup's own nodes come from LDS (most searches stay within a few hundred leaves).
+constexpr int KARRAS_HALO = 896;
+constexpr int KARRAS_WIN = THREADS + 2 * KARRAS_HALO;
+struct Codes {
+    const uint32_t *__restrict__ global;
+    const uint32_t *lds;
+    int64_t winStart;
+    __device__ __forceinline__ uint32_t operator[](int64_t j) const {
+        const int64_t r = j - winStart;
+        return (r >= 0 && r < KARRAS_WIN) ? lds[r] : global[j];
+    }
+};
+__device__ __forceinline__ int delta(const Codes &m, uint32_t mi, int64_t j, int64_t inodeNum) {
     if (j < 0 || j > inodeNum)
         return -1;
     const uint32_t x = mi ^ m[j];
     return x == 0 ? 32 : __clz(static_cast<int>(x));
 }
 
-// lbvh.cu:29-98, one thread per internal node; also records the parent of each child.
+// lbvh.cu:29-98, one thread per internal node. PARENTS also records the parent of each child (an
+// inspection stage; nothing in the build reads it).
+template <bool PARENTS>
 __global__ __launch_bounds__(THREADS) void karras_links_kernel(
-    const uint32_t *__restrict__ mortons, const kk_lbvh_device_data *__restrict__ hdr,
+    const uint32_t *__restrict__ mortonsGlobal, const kk_lbvh_device_data *__restrict__ hdr,
     kk_lbvh_node *__restrict__ nodes, uint32_t *__restrict__ nodeParents,
     uint32_t *__restrict__ leafParents, uint32_t *__restrict__ rangeEnds) {
+    __shared__ uint32_t s_codes[KARRAS_WIN];
     const uint32_t M = hdr->compacted_face_num;
     const int64_t inodeNum = static_cast<int64_t>(M) - 1;
-    const int64_t i = static_cast<int64_t>(blockIdx.x) * THREADS + threadIdx.x;
+    const int64_t blockFirst = static_cast<int64_t>(blockIdx.x) * THREADS;
+    if (blockFirst >= inodeNum)
+        return;
+    Codes mortons{mortonsGlobal, s_codes, blockFirst - KARRAS_HALO};
+    for (int r = threadIdx.x; r < KARRAS_WIN; r += THREADS) {
+        const int64_t j = mortons.winStart + r;
+        s_codes[r] = (j >= 0 && j <= inodeNum) ? mortonsGlobal[j] : 0u;
+    }
+    __syncthreads();
+    const int64_t i = blockFirst + threadIdx.x;
     if (i >= inodeNum)
         return;
     const uint32_t mi = mortons[i];
@@ -370,29 +402,20 @@ __global__ __launch_bounds__(THREADS) void karras_links_kernel(
     uint32_t lft = static_cast<uint32_t>(split);
     uint32_t rht = static_cast<uint32_t>(split + 1);
     const int64_t lo = i < iMax ? i : iMax, hi = i < iMax ? iMax : i;
-    if (lo == split) {
-        leafParents[lft] = static_cast<uint32_t>(i);
+    if (PARENTS) {
+        (lo == split ? leafParents : nodeParents)[lft] = static_cast<uint32_t>(i);
+        (hi == split + 1 ? leafParents : nodeParents)[rht] = static_cast<uint32_t>(i);
+        if (i == 0)
+            nodeParents[0] = 0xFFFFFFFFu;
+    }
+    if (lo == split)
         lft |= LEAF;
-    } else
-        nodeParents[lft] = static_cast<uint32_t>(i);
-    if (hi == split + 1) {
-        leafParents[rht] = static_cast<uint32_t>(i);
+    if (hi == split + 1)
         rht |= LEAF;
-    } else
-        nodeParents[rht] = static_cast<uint32_t>(i);
-    nodes[i].lft = lft;
-    nodes[i].rht = rht;
+    *reinterpret_cast<uint2 *>(&nodes[i].lft) = make_uint2(lft, rht);
     rangeEnds[i] = static_cast<uint32_t>(iMax); // the node covers leaves [min(i, iMax), max(i, iMax)]
-    if (i == 0)
-        nodeParents[0] = 0xFFFFFFFFu;
 }
 
-__device__ __forceinline__ AABB load_box(const float *p) {
-    AABB b;
-    b.minPos = {p[0], p[1], p[2]};
-    b.maxPos = {p[3], p[4], p[5]};
-    return b;
-}
 
 // Internal-node boxes without a bottom-up dependency chain.
 //
@@ -416,14 +439,6 @@ constexpr int MAX_TOTAL_LEVELS = 7;
 constexpr int REFIT_SPAN_BLOCKS = 1024;
 static_assert(REFIT_LEAVES == (1 << REFIT_LOG) && REFIT_LOG == 2 * RADIX_LOG, "window = 32^2 leaves");
 
-__device__ __forceinline__ void store_box(float *p, const AABB &b) {
-    p[0] = b.minPos.x;
-    p[1] = b.minPos.y;
-    p[2] = b.minPos.z;
-    p[3] = b.maxPos.x;
-    p[4] = b.maxPos.y;
-    p[5] = b.maxPos.z;
-}
 
 // Where the totals of each level start (in boxes) inside the totals array; level l has
 // ceil(capacity / 32^l) entries. Level 0 is the leaf boxes themselves and is not stored here.
@@ -617,7 +632,7 @@ __global__ __launch_bounds__(THREADS) void refit_span_kernel(
 
 struct Ws {
     kk_lbvh_ws_layout pub;
-    size_t params, partials, keys1, vals1, blockCounts, topCount, rangeEnds, topList, totals, sortWs;
+    size_t params, partials, keys1, vals1, faceBoxes, blockCounts, topCount, rangeEnds, topList, totals, sortWs;
     size_t sortWsBytes;
     uint32_t headBlocks;
 };
@@ -632,6 +647,7 @@ inline Ws layout(uint32_t N, uint32_t flags) {
     w.pub.sorted_mortons = c.take(4 * n); // keys0: Morton codes, sorted in place by the 4 passes
     w.keys1 = c.take(4 * n);
     w.vals1 = c.take(4 * n);
+    w.faceBoxes = c.take(24 * n);
     w.pub.unsorted_mortons = (flags & KK_LBVH_KEEP_STAGES) ? c.take(4 * n) : 0;
     w.pub.unique_mortons = c.take(4 * n);
     w.pub.leaf_aabbs = c.take(24 * n);
@@ -686,6 +702,7 @@ extern "C" int kk_lbvh_build(const float *d_positions, uint32_t vert_num,
     auto *keys0 = reinterpret_cast<uint32_t *>(b + w.pub.sorted_mortons);
     auto *keys1 = reinterpret_cast<uint32_t *>(b + w.keys1);
     auto *vals1 = reinterpret_cast<uint32_t *>(b + w.vals1);
+    auto *faceBoxes = reinterpret_cast<float *>(b + w.faceBoxes);
     auto *uniq = reinterpret_cast<uint32_t *>(b + w.pub.unique_mortons);
     auto *leafAABBs = reinterpret_cast<float *>(b + w.pub.leaf_aabbs);
     auto *nodeParents = reinterpret_cast<uint32_t *>(b + w.pub.node_parents);
@@ -706,7 +723,7 @@ extern "C" int kk_lbvh_build(const float *d_positions, uint32_t vert_num,
                                                   params, d_out);
     KK_LAUNCH_CHECK();
     morton_kernel<<<div_up(N, THREADS), THREADS, 0, stream>>>(d_positions, d_face_pos_idx, N, params,
-                                                              keys0);
+                                                              keys0, faceBoxes);
     KK_LAUNCH_CHECK();
     if (flags & KK_LBVH_KEEP_STAGES)
         KK_HIP_TRY(hipMemcpyAsync(b + w.pub.unsorted_mortons, keys0, 4ull * N,
@@ -727,11 +744,14 @@ extern "C" int kk_lbvh_build(const float *d_positions, uint32_t vert_num,
     KK_LAUNCH_CHECK();
 
     const uint32_t ngrid = div_up(N, THREADS);
-    leaf_aabb_kernel<<<ngrid, THREADS, 0, stream>>>(d_positions, d_face_pos_idx, d_faces,
-                                                    d_compacted, d_out, leafAABBs);
+    leaf_aabb_kernel<<<ngrid, THREADS, 0, stream>>>(faceBoxes, d_faces, d_compacted, d_out, leafAABBs);
     KK_LAUNCH_CHECK();
-    karras_links_kernel<<<ngrid, THREADS, 0, stream>>>(uniq, d_out, d_nodes, nodeParents,
-                                                       leafParents, rangeEnds);
+    if (flags & KK_LBVH_KEEP_STAGES)
+        karras_links_kernel<true><<<ngrid, THREADS, 0, stream>>>(uniq, d_out, d_nodes, nodeParents,
+                                                                 leafParents, rangeEnds);
+    else
+        karras_links_kernel<false><<<ngrid, THREADS, 0, stream>>>(uniq, d_out, d_nodes, nodeParents,
+                                                                  leafParents, rangeEnds);
     KK_LAUNCH_CHECK();
     KK_HIP_TRY(hipMemsetAsync(topCount, 0, 4, stream));
     const TotalsLayout tl = totals_layout(N);

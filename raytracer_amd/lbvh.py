@@ -155,9 +155,9 @@ class LBVH:
             "sortedMortons": self.stage("sorted_mortons", N, np.uint32),
             "uniqueMortons": self.stage("unique_mortons", M, np.uint32),
             "leafAABBs": self.stage("leaf_aabbs", 6 * M, np.float32).reshape(M, 6),
-            "nodeParents": self.stage("node_parents", max(M - 1, 0), np.uint32),
-            "leafParents": self.stage("leaf_parents", M, np.uint32),
         }
-        if keep_stages:
+        if keep_stages:  # stages only a build with keep_stages=True writes
             out["mortons"] = self.stage("unsorted_mortons", N, np.uint32)
+            out["nodeParents"] = self.stage("node_parents", max(M - 1, 0), np.uint32)
+            out["leafParents"] = self.stage("leaf_parents", M, np.uint32)
         return out

@@ -85,6 +85,17 @@ def _compare_build(oracle, pos, tri):
     return bvh, ref
 
 
+def test_build_without_stages_is_the_same_tree():
+    """The production build (no inspection stages kept) writes the same arrays as the inspected one."""
+    pos, tri = syn.triangle_soup(200_000)
+    a, b = LBVH(DEV), LBVH(DEV)
+    a.BuildFrom(pos, tri, keep_stages=True)
+    b.BuildFrom(pos, tri)
+    ha, hb = a.to_host(), b.to_host()
+    for name in ("faces", "compactedFaces", "internalNodes", "leafAABBs", "uniqueMortons"):
+        assert ha[name].tobytes() == hb[name].tobytes(), name
+
+
 def test_build_veach_mis(oracle, veach):
     bvh, ref = _compare_build(oracle, veach["positions"], veach["face_position_indices"])
     assert ref["M"] == 1343
