@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--cpu-rays", type=int, default=262_144, help="rays of the CPU baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-dvr", action="store_true")
+    ap.add_argument("--no-pt", action="store_true")
     return ap.parse_args()
 
 
@@ -227,6 +228,13 @@ def main():
                                     np.array_equal(bvh.d_faces.cpu().numpy().view(np.uint32), ref["faces"]) and
                                     bvh.d_nodes[:(M - 1) * 32].cpu().numpy().tobytes() ==
                                     ref["internalNodes"].tobytes())}
+
+    # ---- path tracer on the reference's scene (1920x1080, 16 spp), one GPU ---------------------------
+    if world == 1 and not args.no_pt:
+        from raytracer_amd import bench_pt
+        pt = bench_pt.run(dev, with_cpu=not args.no_cpu)
+        if pt:
+            out["path_trace"] = pt
 
     # ---- volume path (reported beside the headline value) -------------------------------------------
     if dvr:

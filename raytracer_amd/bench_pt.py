@@ -1,0 +1,71 @@
+"""Path-tracing leg of the benchmark: the veach-mis scene (the reference's only complete scene, arrays
+from tests/golden/veach_mis.npz) at 1920x1080, 16 calls of RayTracer.Render (16 samples per pixel,
+maxPathDepth 4), timed with the scene resident; the CPU checker renders a few row bands of the same
+frame for the baseline and the full-size parity figure."""
+from __future__ import annotations
+
+import os
+import time
+
+import numpy as np
+import torch
+
+from .data import camera as cam
+from .data.scene_setup import make_tracer
+from .ray_tracer import FrameBuffer
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run(dev: str, size=(1920, 1080), spp: int = 16, frames: int = 5, with_cpu: bool = True,
+        cpu_bands: int = 4, band_rows: int = 4) -> dict:
+    path = os.path.join(ROOT, "tests", "golden", "veach_mis.npz")
+    if not os.path.exists(path):
+        return {}
+    d = dict(np.load(path))
+    W, H = size
+    tracer, arr, c, proj = make_tracer(d, W, H, dev)
+    fb = FrameBuffer(W, H, dev)
+
+    def frame():
+        tracer.curr_accu_spp = 1.0  # restart the accumulation
+        for _ in range(spp):
+            tracer.Render(fb)
+
+    frame()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for _ in range(frames):
+        frame()
+    ev1.record()
+    torch.cuda.synchronize()
+    ms = ev0.elapsed_time(ev1) / frames
+    out = {"workload": f"veach-mis {W}x{H}, {spp} spp, maxPathDepth 4",
+           "ms_per_frame": round(ms, 3), "ms_per_sample_pass": round(ms / spp, 4),
+           "Mpaths_per_s": round(W * H * spp / (ms * 1e-3) / 1e6, 1)}
+    if with_cpu:
+        from oracle import kkoracle as ko
+        cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or (os.cpu_count() or 1)
+        ref = ko.lbvh_build(d["positions"], d["face_position_indices"])
+        acc = np.zeros((H, W, 3), np.float32)
+        img = np.zeros((H, W, 4), np.uint8)
+        bands = [(int((i + 0.5) * H / cpu_bands), int((i + 0.5) * H / cpu_bands) + band_rows)
+                 for i in range(cpu_bands)]
+        inv_proj = cam.inverse_projective(proj)
+        t0 = time.perf_counter()
+        for s in range(1, spp + 1):
+            for rows in bands:
+                ko.pt_render_sample(ref, arr, np.eye(4, dtype=np.float32), inv_proj, c.pos,
+                                    c.rotation(), acc, img, float(s), rows=rows)
+        cpu_s = time.perf_counter() - t0
+        n_rows = cpu_bands * band_rows
+        got = tracer.d_accum.cpu().numpy()
+        sel = np.concatenate([np.arange(a, b) for a, b in bands])
+        err = np.abs(got[sel] - acc[sel]).max(axis=2)
+        out["cpu_baseline"] = {"Mpaths_per_s": round(n_rows * W * spp / cpu_s / 1e6, 3), "cores": cores,
+                               "kind": "port", "sample": f"{n_rows} rows of the frame, {spp} spp"}
+        out["parity_vs_cpu"] = {"rows": n_rows, "tolerance": 1e-3,
+                                "frac_pixels_beyond": float((err > 1e-3).mean()),
+                                "mean_abs_err": float(np.abs(got[sel] - acc[sel]).mean())}
+    return out

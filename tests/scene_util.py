@@ -1,30 +1,3 @@
-"""Builds the veach-mis path-tracing set-up from the committed fixture the way app/rt_lbvh.cpp:163-263
-does (materials per group, sphere lights, camera, 60-degree projection, identity world-to-scene)."""
-import numpy as np
-
-from raytracer_amd import ray_tracer as rt
-from raytracer_amd.data import camera as cam
-
-
-def veach_arrays(d):
-    n = d["face_position_indices"].shape[0]
-    gs = d["grp_start_face_indices"]
-    tris = np.zeros(n, rt.TRIANGLE_DTYPE)
-    tris["normIdx"] = d["face_normal_indices"]
-    tris["texCoordIdx"] = d["face_tex_coord_indices"]
-    tris["grpIdx"] = np.searchsorted(gs[1:], np.arange(n), side="right")
-    mats = rt.stack_structs(
-        [rt.create_material(d["mat_kd"][g], d["mat_ks"][g], d["mat_tr"][g], d["mat_ni"][g],
-                            d["mat_ns"][g], d["mat_emission"][g]) for g in range(len(gs))],
-        rt.MATERIAL_DTYPE)
-    lights = rt.stack_structs(
-        [rt.create_sphere_light(d["light_r"][i], d["light_o"][i], d["light_radiance"][i])
-         for i in range(len(d["light_r"]))], rt.LIGHT_DTYPE)
-    return dict(triangles=tris, tri=d["face_position_indices"], positions=d["positions"],
-                normals=d["normals"], lights=lights, materials=mats)
-
-
-def veach_camera(d, W, H):
-    c = cam.FPSCamera(d["cam_eye"], d["cam_lookat"], d["cam_up"])
-    proj = cam.perspective_fov(cam.radians(60.0), W, H, 1.0, 3.0)
-    return c, proj
+"""The veach-mis path-tracing set-up used by several tests (kept in the package so the benchmark can
+use it too)."""
+from raytracer_amd.data.scene_setup import veach_arrays, veach_camera  # noqa: F401
