@@ -148,10 +148,12 @@ def main():
     torch.cuda.synchronize()
     kernel_ms = ev0.elapsed_time(ev1) / K
 
-    dvr = None
+    dvr = dvr_head = None
     if not args.no_dvr:
         from raytracer_amd import bench_dvr
         dvr = bench_dvr.run(dev, world, rank, dist, with_cpu=not args.no_cpu)
+        dvr_head = bench_dvr.run(dev, world, rank, dist, with_cpu=not args.no_cpu, workload="head",
+                                 dim=(128, 256, 256), size=(1920, 1080), cpu_rows=16)
 
     if rank != 0:
         if dist:
@@ -240,6 +242,8 @@ def main():
     if dvr:
         out["dvr"] = dvr
         out["dvr_fps_4k"] = dvr["fps"]
+    if dvr_head:
+        out["dvr_head_1080p"] = dvr_head
 
     print(json.dumps(out))
     if dist:

@@ -13,7 +13,7 @@ import torch
 
 from . import synthetic as syn
 from .data import camera as cam
-from .data.transfer_function import README_KINGSNAKE_TF, TransferFunction
+from .data.transfer_function import README_HEAD_TF, README_KINGSNAKE_TF, TransferFunction
 from .dpbx_vdb import DepthBoxVDB, Volume
 from .ray_caster import FrameBuffer, RayCaster, TransferFunctionTable
 
@@ -21,14 +21,19 @@ HBM_PEAK_GBPS = 8000.0
 
 
 def run(dev: str, world: int, rank: int, dist=None, frames: int = 120, warmup: int = 8,
-        dim=(1024, 1024, 795), size=(3840, 2160), cpu_rows: int = 24, with_cpu: bool = True) -> dict:
-    tf = TransferFunction(README_KINGSNAKE_TF)
+        dim=(1024, 1024, 795), size=(3840, 2160), cpu_rows: int = 24, with_cpu: bool = True,
+        workload: str = "kingsnake") -> dict:
+    """workload "kingsnake": the 4K case above. "head": Head-shape 128x256x256 uint8 volume, README Head
+    transfer function, spacing (2, 1, 1), 1920x1080 (pass dim and size accordingly)."""
+    head = workload == "head"
+    tf = TransferFunction(README_HEAD_TF if head else README_KINGSNAKE_TF)
     W, H = size
     vdb = DepthBoxVDB(dev)
     build = {}
     vol_t = None
     if rank == 0:
-        vol_t = syn.kingsnake_volume_torch(dim, dev)
+        vol_t = (torch.from_numpy(syn.head_volume(dim)).to(dev) if head
+                 else syn.kingsnake_volume_torch(dim, dev))
         t0 = time.perf_counter()
         vdb.BuildFrom(Volume(vol_t, dev), tf.empty_scalar_ranges, apron_wid=1, log2_dims=(5, 4, 3),
                       use_depth_box=True)
@@ -52,7 +57,7 @@ def run(dev: str, world: int, rank: int, dist=None, frames: int = 120, warmup: i
         dist.barrier()
         bcast_ms = (time.perf_counter() - t0) * 1e3
 
-    scales = cam.volume_scales((1, 1, 1), dim)
+    scales = cam.volume_scales((2, 1, 1) if head else (1, 1, 1), dim)
     caster = RayCaster(dev)
     caster.SetWorldToScene(cam.world_to_scene(scales))
     caster.SetDepthBoxVDB(vdb)
@@ -98,7 +103,8 @@ def run(dev: str, world: int, rank: int, dist=None, frames: int = 120, warmup: i
         wall = float(tt.item())
     if rank != 0:
         return {}
-    out = {"workload": f"Kingsnake-shape {dim[0]}x{dim[1]}x{dim[2]} uint8, {W}x{H}, orbit 0.5 deg/frame",
+    out = {"workload": f"{'Head' if head else 'Kingsnake'}-shape {dim[0]}x{dim[1]}x{dim[2]} uint8, {W}x{H}, "
+                       f"orbit 0.5 deg/frame",
            "fps": round(frames / wall, 2), "ms_per_frame": round(wall * 1e3 / frames, 4), "frames": frames,
            "n_gpus": world, "vdb_build": build}
     if bcast_ms is not None:

@@ -71,6 +71,97 @@ __global__ __launch_bounds__(THREADS) void classify_kernel(const T *__restrict__
     }
 }
 
+// The same fill for bricks whose padded edge fits a 64-bit mask (A <= 64, every configuration the
+// reference's applications use): the brick's A^3 voxels are staged in LDS once; one bit per voxel
+// ("not in an empty scalar range") is packed into rows along x, y and z, so the inward march of a
+// depth-shell voxel - "first position whose 3 x 3 window holds a non-empty voxel" - is the OR of nine
+// row masks and a count of trailing / leading zeros.
+template <typename T>
+__global__ __launch_bounds__(THREADS) void fill_atlas_lds_kernel(const T *__restrict__ vol, int dx,
+                                                                 int dy, int dz,
+                                                                 const kk_vdb_node *__restrict__ leaves,
+                                                                 int B, int apronWid, int apronDepWid,
+                                                                 Ranges<T> rngs, T *__restrict__ atlas) {
+    extern __shared__ __align__(16) unsigned char s_raw[];
+    const int A = B + 2 * apronDepWid;
+    const int A2 = A * A;
+    const size_t brickVox = static_cast<size_t>(A) * A2;
+    unsigned long long *s_mask = reinterpret_cast<unsigned long long *>(s_raw); // [3][A][A]
+    T *s_vox = reinterpret_cast<T *>(s_raw + sizeof(unsigned long long) * 3 * A2);
+    const kk_vdb_node leaf = leaves[blockIdx.x];
+    T *__restrict__ out = atlas + brickVox * blockIdx.x;
+    const bool depthBox = apronDepWid != apronWid;
+    const int tid = threadIdx.x;
+    for (int v = tid; v < static_cast<int>(brickVox); v += THREADS) {
+        const int ax = v % A, ay = (v / A) % A, az = v / A2;
+        s_vox[v] = voxelAt(vol, dx, dy, dz, leaf.pos[0] + ax - apronDepWid, leaf.pos[1] + ay - apronDepWid,
+                           leaf.pos[2] + az - apronDepWid);
+    }
+    __syncthreads();
+    if (!depthBox) {
+        for (int v = tid; v < static_cast<int>(brickVox); v += THREADS)
+            out[v] = s_vox[v];
+        return;
+    }
+    // row r of direction d: bit i = voxel i along d is not empty. Rows are indexed [outer][inner]:
+    // along x (outer z, inner y), along y (outer z, inner x), along z (outer y, inner x).
+    for (int r = tid; r < 3 * A2; r += THREADS) {
+        const int d = r / A2, outer = (r % A2) / A, inner = r % A;
+        int base, step;
+        if (d == 0) {
+            base = outer * A2 + inner * A;
+            step = 1;
+        } else if (d == 1) {
+            base = outer * A2 + inner;
+            step = A;
+        } else {
+            base = outer * A + inner;
+            step = A2;
+        }
+        unsigned long long m = 0;
+        for (int i = 0; i < A; ++i)
+            m |= static_cast<unsigned long long>(rangeHits(s_vox[base + i * step], rngs) == 0) << i;
+        s_mask[r] = m;
+    }
+    __syncthreads();
+    const unsigned long long field = (1ull << (B - 1)) - 1ull; // the B - 1 positions a march can stop at
+    for (int v = tid; v < static_cast<int>(brickVox); v += THREADS) {
+        const int ax = v % A, ay = (v / A) % A, az = v / A2;
+        const int dirX = ax == 0 ? 1 : ax == A - 1 ? -1 : 0;
+        const int dirY = ay == 0 ? 1 : ay == A - 1 ? -1 : 0;
+        const int dirZ = az == 0 ? 1 : az == A - 1 ? -1 : 0;
+        const int faces = (dirX != 0) + (dirY != 0) + (dirZ != 0);
+        T value;
+        if (faces == 0)
+            value = s_vox[v];
+        else if (faces > 1)
+            value = 0;
+        else {
+            // the 3 x 3 window spans the two other axes; (o, i) = the centre's row coordinates
+            const int d = dirX != 0 ? 0 : dirY != 0 ? 1 : 2;
+            const int o = d == 2 ? ay : az, i = d == 0 ? ay : ax;
+            const int dir = dirX + dirY + dirZ;
+            const unsigned long long *rows = s_mask + d * A2;
+            unsigned long long w = 0;
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+                w |= rows[(o + t / 3 - 1) * A + (i + t % 3 - 1)];
+            int dep = B - 1;
+            if (dir > 0) { // from brick position 0 upwards: positions 0 .. B - 2
+                const unsigned long long f = (w >> apronDepWid) & field;
+                if (f)
+                    dep = __ffsll(static_cast<long long>(f)) - 1;
+            } else { // from brick position B - 1 downwards: positions B - 1 .. 1
+                const unsigned long long f = (w >> (apronDepWid + 1)) & field;
+                if (f)
+                    dep = (B - 2) - (63 - __clzll(static_cast<long long>(f)));
+            }
+            value = static_cast<T>(dep);
+        }
+        out[v] = value;
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(THREADS) void fill_atlas_kernel(const T *__restrict__ vol, int dx, int dy,
                                                              int dz, const kk_vdb_node *__restrict__ leaves,
@@ -166,9 +257,22 @@ int fillAtlas(const T *d_volume, uint32_t dx, uint32_t dy, uint32_t dz, const kk
     if (rc != KK_OK)
         return rc;
     const kk_vdb_param &p = plan->param;
-    fill_atlas_kernel<T><<<plan->leaf_num, THREADS, 0, static_cast<hipStream_t>(stream)>>>(
-        d_volume, dx, dy, dz, d_node_pools + p.node_starts[0], p.dims[0], p.apron_wid, p.apron_dep_wid,
-        r, d_atlas);
+    const size_t A = static_cast<size_t>(p.dims[0]) + 2u * p.apron_dep_wid;
+    const size_t lds = 3 * A * A * sizeof(unsigned long long) + A * A * A * sizeof(T);
+    if (A <= 64 && p.dims[0] >= 2 && lds <= 150 * 1024) {
+        static bool raised[2] = {false, false}; // the default dynamic LDS limit is 64 KB
+        if (!raised[sizeof(T) - 1]) {
+            KK_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&fill_atlas_lds_kernel<T>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+            raised[sizeof(T) - 1] = true;
+        }
+        fill_atlas_lds_kernel<T><<<plan->leaf_num, THREADS, lds, static_cast<hipStream_t>(stream)>>>(
+            d_volume, dx, dy, dz, d_node_pools + p.node_starts[0], p.dims[0], p.apron_wid,
+            p.apron_dep_wid, r, d_atlas);
+    } else
+        fill_atlas_kernel<T><<<plan->leaf_num, THREADS, 0, static_cast<hipStream_t>(stream)>>>(
+            d_volume, dx, dy, dz, d_node_pools + p.node_starts[0], p.dims[0], p.apron_wid,
+            p.apron_dep_wid, r, d_atlas);
     KK_LAUNCH_CHECK();
     return KK_OK;
 }
