@@ -40,6 +40,68 @@ template <typename T> __device__ __forceinline__ uint32_t rangeHits(T v, const R
     return c;
 }
 
+// Wide form of the classification for rows that can be read in aligned 16-byte pieces (dx a multiple
+// of 16 / sizeof(T), 16-byte aligned volume): one workgroup takes GROUP bricks that are neighbours
+// along x, so that every 128-byte line of the volume is fetched once and used whole (a single brick's
+// 32-byte rows would each pull a whole line, four times over the kernel).
+template <typename T, int GROUP>
+__global__ __launch_bounds__(THREADS) void classify_wide_kernel(const T *__restrict__ vol, int dx, int dy,
+                                                                int dz, int log2B, uint32_t lx,
+                                                                uint32_t ly, Ranges<T> rngs,
+                                                                uint32_t *__restrict__ leafValid) {
+    constexpr int PER = 16 / sizeof(T); // voxels per 16-byte piece
+    __shared__ uint32_t s_hits[GROUP];
+    const int B = 1 << log2B;
+    const uint32_t groupsX = (lx + GROUP - 1) / GROUP;
+    const uint32_t gx = blockIdx.x % groupsX, gy = (blockIdx.x / groupsX) % ly, gz = blockIdx.x / (groupsX * ly);
+    const int x0 = static_cast<int>(gx * GROUP) << log2B, y0 = static_cast<int>(gy) << log2B,
+              z0 = static_cast<int>(gz) << log2B;
+    if (threadIdx.x < GROUP)
+        s_hits[threadIdx.x] = 0;
+    __syncthreads();
+    const int piecesPerRow = GROUP * B / PER, piecesPerBrick = B / PER;
+    const int pieceNum = piecesPerRow * B * B;
+    // a thread's pieces all belong to one brick when THREADS is a multiple of piecesPerRow
+    uint32_t hits[GROUP];
+#pragma unroll
+    for (int g = 0; g < GROUP; ++g)
+        hits[g] = 0;
+    for (int p = threadIdx.x; p < pieceNum; p += THREADS) {
+        const int px = p % piecesPerRow, row = p / piecesPerRow;
+        const int y = y0 + (row & (B - 1)), z = z0 + (row >> log2B);
+        const int x = x0 + px * PER;
+        const int g = px / piecesPerBrick;
+        uint32_t h = 0;
+        if (y < dy && z < dz && x < dx) { // dx is a multiple of PER: a piece is inside or outside
+            const uint4 w = *reinterpret_cast<const uint4 *>(vol + (static_cast<size_t>(z) * dy + y) * dx + x);
+            const T *v = reinterpret_cast<const T *>(&w);
+#pragma unroll
+            for (int i = 0; i < PER; ++i)
+                h += rangeHits(v[i], rngs);
+        } else
+            h = PER * rangeHits(static_cast<T>(0), rngs); // outside the volume reads as 0
+#pragma unroll
+        for (int gg = 0; gg < GROUP; ++gg)
+            hits[gg] += gg == g ? h : 0u;
+    }
+#pragma unroll
+    for (int g = 0; g < GROUP; ++g) {
+        uint32_t h = hits[g];
+        for (int o = 32; o > 0; o >>= 1)
+            h += __shfl_xor(h, o, 64);
+        if ((threadIdx.x & 63) == 0 && h != 0)
+            atomicAdd(&s_hits[g], h);
+    }
+    __syncthreads();
+    if (threadIdx.x < GROUP) {
+        const uint32_t bx = gx * GROUP + threadIdx.x;
+        if (bx < lx) {
+            const uint32_t voxNum = 1u << (3 * log2B);
+            leafValid[(static_cast<size_t>(gz) * ly + gy) * lx + bx] = s_hits[threadIdx.x] == voxNum ? 0u : 1u;
+        }
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(THREADS) void classify_kernel(const T *__restrict__ vol, int dx, int dy,
                                                            int dz, int log2B, uint32_t lx, uint32_t ly,
@@ -241,8 +303,16 @@ int classify(const T *d_volume, uint32_t dx, uint32_t dy, uint32_t dz, uint32_t 
         return rc;
     const uint32_t B = 1u << log2B;
     const uint32_t lx = (dx + B - 1) / B, ly = (dy + B - 1) / B, lz = (dz + B - 1) / B;
-    classify_kernel<T><<<lx * ly * lz, THREADS, 0, static_cast<hipStream_t>(stream)>>>(
-        d_volume, dx, dy, dz, log2B, lx, ly, r, d_leaf_valid);
+    constexpr uint32_t GROUP = 4, PER = 16 / sizeof(T);
+    const bool wide = dx % PER == 0 && (reinterpret_cast<uintptr_t>(d_volume) & 15u) == 0 && B >= PER &&
+                      log2B <= 6;
+    if (wide)
+        classify_wide_kernel<T, GROUP><<<((lx + GROUP - 1) / GROUP) * ly * lz, THREADS, 0,
+                                         static_cast<hipStream_t>(stream)>>>(d_volume, dx, dy, dz, log2B,
+                                                                            lx, ly, r, d_leaf_valid);
+    else
+        classify_kernel<T><<<lx * ly * lz, THREADS, 0, static_cast<hipStream_t>(stream)>>>(
+            d_volume, dx, dy, dz, log2B, lx, ly, r, d_leaf_valid);
     KK_LAUNCH_CHECK();
     return KK_OK;
 }
