@@ -147,6 +147,24 @@ def main():
     ev1.record()
     torch.cuda.synchronize()
     kernel_ms = ev0.elapsed_time(ev1) / K
+    # the optional watertight triangle test, same rays: throughput and how often its primitive differs
+    prim_ref = prim.clone()
+    t_ref = t.clone()
+    ev0.record()
+    for _ in range(K):
+        closest_hit(bvh, rays, out=l_out, watertight=True)
+    ev1.record()
+    torch.cuda.synchronize()
+    wt_ms = ev0.elapsed_time(ev1) / K
+    wt_mism = prim != prim_ref
+    wt_same = (~wt_mism) & (prim_ref >= 0)
+    wt_rel = ((t[wt_same] - t_ref[wt_same]).abs() / t_ref[wt_same].abs().clamp_min(1e-30))
+    watertight = {"Mrays_per_s": round(R / (wt_ms * 1e-3) / 1e6, 2),
+                  "prim_mismatch_frac_vs_default": float(wt_mism.float().mean()),
+                  "frac_same_prim_with_rel_t_err_above_1e-5": float((wt_rel > 1e-5).float().mean()),
+                  "max_rel_t_err_same_prim": float(wt_rel.max()) if wt_rel.numel() else 0.0}
+    closest_hit(bvh, rays, out=l_out)  # leave the default results in the output buffers
+    torch.cuda.synchronize()
 
     dvr = dvr_head = None
     if not args.no_dvr:
@@ -187,6 +205,7 @@ def main():
                    "triangles": N, "leaves": M, "rays_per_gpu": R, "parallelism": f"replicated-bvh x{world}"},
         "roofline": roofline,
         "hit_fraction": round(float((prim >= 0).float().mean()), 4),
+        "watertight_option": watertight,
     }
     if build_ms is not None:
         gbps = LBVH_BYTES_PER_TRI * N / (build_ms * 1e-3) / 1e9

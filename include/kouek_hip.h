@@ -153,7 +153,9 @@ int kk_closest_hit(const kk_lbvh_device_data *d_lbvh, const float *d_positions,
  * tree's arrays move. */
 enum {
     KK_TRACE_UNSORTED = 1u,   /* trace in input order */
-    KK_TRACE_REUSE_ORDER = 2u /* the same rays as the previous call with this workspace: keep its order */
+    KK_TRACE_REUSE_ORDER = 2u, /* the same rays as the previous call with this workspace: keep its order */
+    KK_TRACE_WATERTIGHT = 4u   /* watertight ray-triangle test (Woop, Benthin, Wald 2013) instead of the
+                                  reference's Moeller-Trumbore: hits may differ on grazing rays */
 };
 size_t kk_trace_accel_bytes(uint32_t face_num, uint32_t compacted_face_num);
 /* d_accel: 256-byte aligned device buffer of kk_trace_accel_bytes(). */

@@ -68,6 +68,7 @@ KK_LBVH_KEEP_STAGES = 1
 KK_TRAVERSE_ORDERED = 0
 KK_TRACE_UNSORTED = 1
 KK_TRACE_REUSE_ORDER = 2
+KK_TRACE_WATERTIGHT = 4
 
 _lib = None
 

@@ -335,21 +335,79 @@ enum : uint32_t { MODE_FAST = 0, MODE_CAREFUL = 1, MODE_CHAIN = 2 };
 // leaf's parent box passes the reference's slab test is checked once, for the final hit, when the ray
 // retires (MODE_FAST). A ray being re-traced after that check failed checks every hit it takes
 // (MODE_CAREFUL); a ray with a zero direction component checks the whole chain of boxes (MODE_CHAIN).
-template <bool COUNT>
+//
+// WATERTIGHT replaces the reference's Moeller-Trumbore test by the shear-and-scale test of Woop,
+// Benthin and Wald (2013), two-sided, with its double-precision fallback on an edge: a ray through a
+// shared edge or vertex cannot slip between two triangles. It is an option, not the default, because
+// its hit / miss decisions differ from the reference's on grazing rays.
+struct Shear {
+    int kx, ky, kz;
+    float sx, sy, sz;
+};
+__device__ __forceinline__ Shear make_shear(f3 d) {
+    Shear s;
+    const float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
+    s.kz = (ax > ay) ? (ax > az ? 0 : 2) : (ay > az ? 1 : 2);
+    s.kx = s.kz + 1 == 3 ? 0 : s.kz + 1;
+    s.ky = s.kx + 1 == 3 ? 0 : s.kx + 1;
+    if (d[s.kz] < 0.f) {
+        const int t = s.kx;
+        s.kx = s.ky;
+        s.ky = t;
+    }
+    s.sx = d[s.kx] / d[s.kz];
+    s.sy = d[s.ky] / d[s.kz];
+    s.sz = 1.f / d[s.kz];
+    return s;
+}
+// returns t (< 0: miss); bx, by = weights of v1 and v2 like the reference's barycentrics
+__device__ __forceinline__ float hit_watertight(const Shear &s, f3 org, f3 v0, f3 v1, f3 v2, float &bx,
+                                                float &by) {
+    const f3 A = v0 - org, B = v1 - org, C = v2 - org;
+    const float Ax = A[s.kx] - s.sx * A[s.kz], Ay = A[s.ky] - s.sy * A[s.kz];
+    const float Bx = B[s.kx] - s.sx * B[s.kz], By = B[s.ky] - s.sy * B[s.kz];
+    const float Cx = C[s.kx] - s.sx * C[s.kz], Cy = C[s.ky] - s.sy * C[s.kz];
+    float U = Cx * By - Cy * Bx, V = Ax * Cy - Ay * Cx, W = Bx * Ay - By * Ax;
+    if (U == 0.f || V == 0.f || W == 0.f) {
+        U = static_cast<float>(static_cast<double>(Cx) * By - static_cast<double>(Cy) * Bx);
+        V = static_cast<float>(static_cast<double>(Ax) * Cy - static_cast<double>(Ay) * Cx);
+        W = static_cast<float>(static_cast<double>(Bx) * Ay - static_cast<double>(By) * Ax);
+    }
+    if ((U < 0.f || V < 0.f || W < 0.f) && (U > 0.f || V > 0.f || W > 0.f))
+        return -1.f;
+    const float det = U + V + W;
+    if (det == 0.f)
+        return -1.f;
+    const float Az = s.sz * A[s.kz], Bz = s.sz * B[s.kz], Cz = s.sz * C[s.kz];
+    const float T = U * Az + V * Bz + W * Cz;
+    const float inv = 1.f / det;
+    const float t = T * inv;
+    if (!(t >= 0.f))
+        return -1.f;
+    bx = V * inv;
+    by = W * inv;
+    return t;
+}
+
+template <bool COUNT, bool WATERTIGHT>
 __device__ __forceinline__ void test_run(const TriRec *__restrict__ recs,
                                          const kk_lbvh_node *__restrict__ nodes,
                                          const uint32_t *__restrict__ parents, const RayState &r,
                                          uint32_t mode, uint32_t k0, uint32_t n, trav::Hit &best,
                                          uint32_t &triTests) {
     const Ray ray{r.pos, r.dir};
+    Shear shear{};
+    if (WATERTIGHT && n != 0u)
+        shear = make_shear(r.dir);
     for (uint32_t k = k0; k < k0 + n; ++k) {
         const uint4 *p = reinterpret_cast<const uint4 *>(recs + k);
         const uint4 a = p[0], b = p[1], c = p[2];
         float bx = 0.f, by = 0.f;
-        const float t = HitTriangle(
-            ray, F3(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z)),
-            F3(__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z)),
-            F3(__uint_as_float(c.x), __uint_as_float(c.y), __uint_as_float(c.z)), bx, by);
+        const f3 v0 = F3(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z));
+        const f3 v1 = F3(__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z));
+        const f3 v2 = F3(__uint_as_float(c.x), __uint_as_float(c.y), __uint_as_float(c.z));
+        const float t = WATERTIGHT ? hit_watertight(shear, r.pos, v0, v1, v2, bx, by)
+                                   : HitTriangle(ray, v0, v1, v2, bx, by);
         if (COUNT)
             ++triTests;
         if (t >= 0.f && (t < best.t || (t == best.t && k < best.k))) {
@@ -383,7 +441,7 @@ __device__ __forceinline__ void cswap(float &ka, uint32_t &ia, float &kb, uint32
 // Taking a better triangle hit without checking its parent box first is safe: the limit that prunes
 // the walk is never below the final t, so nothing closer is skipped; if the final hit itself fails
 // the check, the lane walks the ray again with every hit checked as it is taken.
-template <bool COUNT>
+template <bool COUNT, bool WATERTIGHT>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(5, 5))) void closest_hit_accel_kernel(
     const Header *__restrict__ hdr, const Node4 *__restrict__ node4, const TriRec *__restrict__ recs,
     const float *__restrict__ rays, const uint32_t *__restrict__ order, uint32_t rayNum,
@@ -630,8 +688,8 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(5, 5)))
             const int stepping = __popcll(__ballot(active && (pendC0 | pendC1) == 0u));
             if (parked != 0 && (parked >= PARK_MIN || stepping < STEP_MIN)) {
                 if ((pendC0 | pendC1) != 0u) {
-                    test_run<COUNT>(recs, nodes, parents, ray, mode, pendK0, pendC0, best, triTests);
-                    test_run<COUNT>(recs, nodes, parents, ray, mode, pendK1, pendC1, best, triTests);
+                    test_run<COUNT, WATERTIGHT>(recs, nodes, parents, ray, mode, pendK0, pendC0, best, triTests);
+                    test_run<COUNT, WATERTIGHT>(recs, nodes, parents, ray, mode, pendK1, pendC1, best, triTests);
                     pendC0 = pendC1 = 0u;
                 }
             }
@@ -722,7 +780,8 @@ extern "C" int kk_closest_hit_accel(const void *d_accel, uint32_t face_num,
     KK_REQUIRE(d_accel && d_rays && d_t && d_bary && d_prim && d_workspace, "null pointer");
     KK_REQUIRE(face_num > 0 && compacted_face_num > 0 && compacted_face_num <= face_num,
                "tree sizes out of range");
-    KK_REQUIRE((flags & ~static_cast<uint32_t>(KK_TRACE_UNSORTED | KK_TRACE_REUSE_ORDER)) == 0,
+    KK_REQUIRE((flags & ~static_cast<uint32_t>(KK_TRACE_UNSORTED | KK_TRACE_REUSE_ORDER |
+                                               KK_TRACE_WATERTIGHT)) == 0,
                "unknown flag");
     if (ray_num == 0)
         return KK_OK;
@@ -758,14 +817,23 @@ extern "C" int kk_closest_hit_accel(const void *d_accel, uint32_t face_num,
         grid = MAX_GRID;
     uint2 *spill = reinterpret_cast<uint2 *>(b + w.spill);
     const auto *parents = reinterpret_cast<const uint32_t *>(ab + l.parents);
-    if (d_counters)
-        closest_hit_accel_kernel<true><<<grid, THREADS, 0, stream>>>(
-            hdr, node4, recs, d_rays, order, ray_num, d_t, d_bary, d_prim, rayCounter, parents,
-            spill, d_counters);
-    else
-        closest_hit_accel_kernel<false><<<grid, THREADS, 0, stream>>>(
-            hdr, node4, recs, d_rays, order, ray_num, d_t, d_bary, d_prim, rayCounter, parents,
-            spill, nullptr);
+    const bool wt = (flags & KK_TRACE_WATERTIGHT) != 0;
+#define KK_LAUNCH_TRACE(COUNT, WT)                                                                 \
+    closest_hit_accel_kernel<COUNT, WT><<<grid, THREADS, 0, stream>>>(                              \
+        hdr, node4, recs, d_rays, order, ray_num, d_t, d_bary, d_prim, rayCounter, parents, spill,  \
+        d_counters)
+    if (d_counters) {
+        if (wt)
+            KK_LAUNCH_TRACE(true, true);
+        else
+            KK_LAUNCH_TRACE(true, false);
+    } else {
+        if (wt)
+            KK_LAUNCH_TRACE(false, true);
+        else
+            KK_LAUNCH_TRACE(false, false);
+    }
+#undef KK_LAUNCH_TRACE
     KK_LAUNCH_CHECK();
     return KK_OK;
 }

@@ -113,6 +113,7 @@ class LBVH:
         synchronisation)."""
         l = _lib.lib()
         self._host_dd = None
+        self._accel_stale = True  # the trace-side repacking describes the previous tree
         with torch.cuda.device(self.device):
             _lib.check(l.kk_lbvh_build(self.d_positions.data_ptr(), self.d_positions.shape[0],
                                        self.d_face_pos_idx.data_ptr(), self.face_num,
@@ -122,7 +123,7 @@ class LBVH:
                                        _lib.current_stream_ptr()), "kk_lbvh_build")
 
     def trace_accel(self, rebuild: bool = False):
-        """The trace-side layout of this tree (64-byte two-box node records + 48-byte triangle records),
+        """The trace-side layout of this tree (64-byte records of four quantised boxes + 48-byte triangle records),
         built on first use on the current stream; `rebuild` repacks it over the same buffer."""
         l = _lib.lib()
         N, M = self.face_num, self.GetDeviceData()["compactedFaceNum"]
@@ -130,7 +131,8 @@ class LBVH:
             self.d_accel = torch.empty(l.kk_trace_accel_bytes(N, M), dtype=torch.uint8, device=self.device)
             self._accel_sizes = (N, M)
             rebuild = True
-        if rebuild:
+        if rebuild or getattr(self, "_accel_stale", False):
+            self._accel_stale = False
             with torch.cuda.device(self.device):
                 _lib.check(l.kk_trace_accel_build(self.GetDeivceDataDevicePtr(), self.d_positions.data_ptr(),
                                                   self.d_face_pos_idx.data_ptr(), N, M,

@@ -12,13 +12,14 @@ from .lbvh import LBVH
 
 
 def closest_hit(lbvh: LBVH, rays, count: bool = False, out=None, layout: str = "trace", sort: bool = True,
-                reuse_order: bool = False):
+                reuse_order: bool = False, watertight: bool = False):
     """Traces rays [R,6] (pos, dir) through a built LBVH with rayCastLBVH<false>'s result semantics
     (src/ray_tracer/ray_tracer_render.cu:192-270). Returns torch tensors (t [R], bary [R,2],
     prim [R] int32 with -1 = miss) and, when `count`, a dict of work counters.
     layout "trace" walks the repacked two-box records (rays in Morton order unless sort=False);
     layout "build" walks the build's own 32-byte nodes. Both give the same hits. reuse_order keeps the
-    ray order found by the previous call with the same `out` workspace (same rays)."""
+    ray order found by the previous call with the same `out` workspace (same rays). watertight swaps the
+    triangle test for the watertight one (trace layout only; hits may differ on grazing rays)."""
     l = _lib.lib()
     dev = lbvh.device
     d_rays = rays if isinstance(rays, torch.Tensor) else torch.from_numpy(
@@ -42,8 +43,9 @@ def closest_hit(lbvh: LBVH, rays, count: bool = False, out=None, layout: str = "
             N, M = lbvh._accel_sizes
             _lib.check(l.kk_closest_hit_accel(accel.data_ptr(), N, M, d_rays.data_ptr(), R, t.data_ptr(),
                                               bary.data_ptr(), prim.data_ptr(),
-                                              _lib.KK_TRACE_REUSE_ORDER if reuse_order else
-                                              (0 if sort else _lib.KK_TRACE_UNSORTED),
+                                              (_lib.KK_TRACE_REUSE_ORDER if reuse_order else
+                                               (0 if sort else _lib.KK_TRACE_UNSORTED)) |
+                                              (_lib.KK_TRACE_WATERTIGHT if watertight else 0),
                                               counters.data_ptr() if count else None, ws.data_ptr(),
                                               ws.numel(), _lib.current_stream_ptr()),
                        "kk_closest_hit_accel")

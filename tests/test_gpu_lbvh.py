@@ -273,3 +273,49 @@ def test_closest_hit_single_leaf(oracle):
         t, bary, prim = closest_hit(bvh, rays, layout=layout)
         assert prim.cpu().numpy().tolist() == [0, -1]
         assert float(t[0]) == 1.0
+
+
+def test_watertight_option_agrees_except_on_grazing_rays(oracle):
+    """The optional watertight triangle test: same primitive as the reference's test except for a small
+    fraction of rays (edge grazes), hit distance within 1e-5 relative where the primitive agrees, and no
+    ray slips through the shared edges of a closed mesh."""
+    pos, tri = syn.triangle_soup(100_000)
+    rays = syn.incoherent_rays(65_536)
+    bvh = LBVH(DEV)
+    bvh.BuildFrom(pos, tri)
+    t0, b0, p0 = [x.cpu().numpy() for x in closest_hit(bvh, rays)]
+    t1, b1, p1 = [x.cpu().numpy() for x in closest_hit(bvh, rays, watertight=True)]
+    mism = p0 != p1
+    assert float(mism.mean()) <= 1e-3, float(mism.mean())
+    same = ~mism & (p0 >= 0)
+    np.testing.assert_allclose(t1[same], t0[same], rtol=1e-5)
+    np.testing.assert_allclose(b1[same], b0[same], atol=1e-3)
+    # a closed, finely tessellated unit cube seen from its centre: every ray must hit something,
+    # including the ones aimed exactly at shared vertices and edges
+    n = 16
+    g = np.linspace(0, 1, n + 1, dtype=np.float32)
+    verts, faces = [], []
+    for axis in range(3):
+        for side in (0.0, 1.0):
+            base = len(verts)
+            for i in range(n + 1):
+                for j in range(n + 1):
+                    p = [0.0, 0.0, 0.0]
+                    p[axis], p[(axis + 1) % 3], p[(axis + 2) % 3] = side, g[i], g[j]
+                    verts.append(p)
+            for i in range(n):
+                for j in range(n):
+                    a = base + i * (n + 1) + j
+                    faces += [[a, a + 1, a + n + 2], [a, a + n + 2, a + n + 1]]
+    verts, faces = np.array(verts, np.float32), np.array(faces, np.uint32)
+    cube = LBVH(DEV)
+    cube.BuildFrom(verts, faces)
+    targets = verts[np.random.default_rng(3).integers(0, len(verts), 20_000)]
+    mid = (verts[faces[:2000, 0]] + verts[faces[:2000, 2]]) / 2  # points on shared diagonals
+    targets = np.concatenate([targets, mid])
+    org = np.full_like(targets, 0.5) + np.float32(0.013)
+    d = targets - org
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    r = np.concatenate([org, d], 1).astype(np.float32)
+    _, _, pw = closest_hit(cube, r, watertight=True)
+    assert int((pw < 0).sum()) == 0
