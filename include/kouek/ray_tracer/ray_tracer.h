@@ -139,8 +139,26 @@ class RayTracer : Noncopyable {
             std::cerr << ErrTag << " at " << __FILE__ << ":" << __LINE__ << ". lbvh is not set.\n";
             return;
         }
+        if (rndrTarget == RenderTarget::None)
+            return;
         if (rndrTarget != RenderTarget::Scene) {
-            std::cerr << ErrTag << " only RenderTarget::Scene is implemented.\n";
+            // inspection targets: one frame, no accumulation (ray_tracer_render.cu:461-558)
+            modified = false;
+            static constexpr int Targets[] = {0,
+                                              KK_RT_TARGET_AABBS,
+                                              KK_RT_TARGET_TRIANGLES,
+                                              KK_RT_TARGET_LIGHTS,
+                                              KK_RT_TARGET_POSITIONS,
+                                              KK_RT_TARGET_NORMALS,
+                                              KK_RT_TARGET_TEXTURE_COORDS};
+            KOUEK_HIP_CHECK(ErrTag.data(),
+                            kk_rt_render_target(reinterpret_cast<const kk_lbvh_device_data *>(
+                                                    lbvh->GetDeivceDataDevicePtr()),
+                                                &scene, &frame, Targets[static_cast<int>(rndrTarget)],
+                                                rndrTo.Get(), rndrSz.x, rndrSz.y, 0, rndrSz.y, nullptr));
+            prevRndrTo = &rndrTo;
+            prevRndrSz = rndrSz;
+            prevRndrTarget = rndrTarget;
             return;
         }
         bool needRedraw = modified;

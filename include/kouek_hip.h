@@ -245,6 +245,23 @@ int kk_pt_render_sample(const kk_lbvh_device_data *d_lbvh, const kk_pt_scene *h_
                         const kk_pt_frame *h_frame, float *d_accum, uint8_t *d_rgba, int width,
                         int height, int y0, int y1, float sample_index, uint32_t seed, void *stream);
 
+/* The other targets of RayTracer::Render (ray_tracer.h RenderTarget; ray_tracer_render.cu:461-558):
+ * one frame of rows [y0, y1) straight into d_rgba, no accumulation. AABBs draws the boxes at tree depth
+ * h_scene->display_tree_height (:8-100); Triangles / Positions / Normals / TextureCoords shade the
+ * closest hit (:508-551, including the reference's use of norms[0] for two weights and of the normals
+ * array under TextureCoords); Lights draws the light shapes (:272-310). */
+enum {
+    KK_RT_TARGET_AABBS = 1,
+    KK_RT_TARGET_TRIANGLES = 2,
+    KK_RT_TARGET_LIGHTS = 3,
+    KK_RT_TARGET_POSITIONS = 4,
+    KK_RT_TARGET_NORMALS = 5,
+    KK_RT_TARGET_TEXTURE_COORDS = 6
+};
+int kk_rt_render_target(const kk_lbvh_device_data *d_lbvh, const kk_pt_scene *h_scene,
+                        const kk_pt_frame *h_frame, int target, uint8_t *d_rgba, int width, int height,
+                        int y0, int y1, void *stream);
+
 /* The first `count` uniforms in (0, 1] of the stream (seed, pixel, sample), for checking the generator. */
 int kk_rng_uniforms(uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t count, float *d_out,
                     void *stream);

@@ -204,6 +204,35 @@ def pt_render_sample(bvh: dict, arrays: dict, w2s, inv_proj, eye_pos, eye_rot, a
                               C.c_int(y1), C.c_float(sample_idx), C.c_uint32(seed))
 
 
+RT_TARGETS = ("Scene", "AABBs", "Triangles", "Lights", "Positions", "Normals", "TextureCoords")
+
+
+def rt_render_target(bvh: dict, arrays: dict, w2s, inv_proj, eye_pos, eye_rot, W: int, H: int,
+                     target: str, display_tree_height: int = 0, rows=None) -> np.ndarray:
+    """One Render call of an inspection target on the CPU -> rgba [H,W,4] u8."""
+    sc = _KoPtScene()
+    keep = {k: np.ascontiguousarray(v) for k, v in arrays.items()}
+    sc.inodes, sc.faces = _vp(bvh["internalNodes"]).value, _vp(bvh["faces"]).value
+    sc.compactedFaces = _vp(bvh["compactedFaces"]).value
+    sc.faceNum, sc.compactedFaceNum = bvh["N"], bvh["M"]
+    sc.positions, sc.facePosIdx = _vp(keep["positions"]).value, _vp(keep["tri"]).value
+    sc.normals, sc.triangles = _vp(keep["normals"]).value, _vp(keep["triangles"]).value
+    sc.materials = _vp(keep["materials"]).value
+    sc.lights = _vp(keep["lights"]).value if keep["lights"].size else None
+    sc.lightNum = int(keep["lights"].size)
+    for name, val in (("w2s", w2s), ("invProj", inv_proj), ("eyePos", eye_pos), ("eyeRot", eye_rot)):
+        arr = getattr(sc, name)
+        for i, x in enumerate(np.asarray(val, np.float32).reshape(-1)):
+            arr[i] = float(x)
+    root = np.ascontiguousarray(bvh["rootAABB"], np.float32)
+    rgba = np.zeros((H, W, 4), np.uint8)
+    y0, y1 = rows if rows is not None else (0, H)
+    lib().ko_rt_render_target(C.byref(sc), _vp(root), C.c_int(display_tree_height),
+                              C.c_int(RT_TARGETS.index(target)), _vp(rgba), C.c_int(W), C.c_int(H),
+                              C.c_int(y0), C.c_int(y1))
+    return rgba
+
+
 def rng_uniforms(seed: int, pixel: int, sample: int, count: int) -> np.ndarray:
     out = np.zeros(count, np.float32)
     lib().ko_rng_uniforms(C.c_uint32(seed), C.c_uint32(pixel), C.c_uint32(sample), C.c_uint32(count),

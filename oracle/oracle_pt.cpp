@@ -1,7 +1,8 @@
 // TEST INFRASTRUCTURE ONLY (see ko_math.h). CPU restatement of the reference's path-tracing frame:
 // ray generation, renderScene, accumulation and RGBA8 output
 // (src/ray_tracer/ray_tracer_render.cu:312-431, 579-638), with Material::BRDF and the light sampling of
-// include/ray_tracer/material.h and the helpers of include/cg/math.h:75-129.
+// include/ray_tracer/material.h and the helpers of include/cg/math.h:75-129; and of the inspection
+// render targets (AABBs, Triangles, Lights, Positions, Normals, TextureCoords; :8-100, 272-310, 461-558).
 //
 // Parity status: the traversal and intersection arithmetic is pinned (oracle_lbvh.cpp). The random
 // stream is NOT the reference's: it draws from cuRAND XORWOW (curand_init(1234, pixel, 0)), which is
@@ -294,6 +295,179 @@ vec3 renderScene(const Scene &s, Rng &rng, Ray ray) {
     return Lo;
 }
 
+// ---- the inspection render targets (src/ray_tracer/ray_tracer_render.cu:8-100, 272-310, 503-556) ----
+
+// static_cast<uint8_t>(float) as the device does it: toward zero into 32 unsigned bits with
+// saturation (negative and NaN -> 0), then the low byte. glm::clamp(x, 0, 255) of a uint8_t is x.
+inline uint8_t ToU8(float v) {
+    uint32_t u = v > 0.f ? (v < 4294967040.f ? static_cast<uint32_t>(v) : 0xFFFFFFFFu) : 0u;
+    return static_cast<uint8_t>(u);
+}
+struct RGBA8 {
+    uint8_t r, g, b, a;
+};
+inline RGBA8 ToRGBA(vec3 c) { return {ToU8(255.f * c.x), ToU8(255.f * c.y), ToU8(255.f * c.z), 255}; }
+
+// include/cg/ray.h:61-86
+struct HitQuadResult {
+    float t, u, v;
+};
+HitQuadResult HitQuad(const Ray &r, vec3 o, vec3 u, vec3 v) {
+    HitQuadResult ret{-1.f, 0.f, 0.f};
+    // glm::intersectRayPlane, 3rd/glm/gtx/intersect.inl:6-26
+    vec3 n = normalize(cross(u, v));
+    float d = dot(r.dir, n);
+    bool hitPlane = false;
+    if (std::fabs(d) > FloatEps) {
+        float tmp = dot(o - r.pos, n) / d;
+        if (tmp > 0.f) {
+            ret.t = tmp;
+            hitPlane = true;
+        }
+    }
+    if (!hitPlane) {
+        ret.t = -1.f;
+        return ret;
+    }
+    vec3 xLocal = r.pos + ret.t * r.dir - o;
+    float lenU = length(u), lenV = length(v);
+    ret.u = dot(xLocal, u / lenU);
+    ret.v = dot(xLocal, v / lenV);
+    if (ret.u < 0.f || ret.u > lenU || ret.v < 0.f || ret.v > lenV)
+        ret.t = -1.f;
+    return ret;
+}
+// include/cg/ray.h:88-106
+HitShell HitSphere(const Ray &r, float rSqr, vec3 o) {
+    vec3 p2o = o - r.pos;
+    float p2oDotDir = dot(p2o, r.dir);
+    if (p2oDotDir < 0.f)
+        return {0.f, -1.f};
+    float qSqr = dot(p2o, p2o) - p2oDotDir * p2oDotDir;
+    if (qSqr > rSqr)
+        return {0.f, -2.f};
+    float p = std::sqrt(rSqr - qSqr);
+    return {gmax(p2oDotDir - p, 0.f), p2oDotDir + 2.f * p};
+}
+
+// ray_tracer_render.cu:8-100
+RGBA8 renderAABB(const Scene &s, const AABB &rootAABB, uint8_t displayTreeHeight, const Ray &eyeRay) {
+    vec3 extent = rootAABB.maxPos - rootAABB.minPos;
+    for (int a = 0; a < 3; ++a)
+        if (extent[a] < FloatEps)
+            extent[a] = FloatEps;
+    HitShell hit{0.f, 0.f};
+    auto hitNode = [&](uint32_t idx) {
+        if (idx & ChildIsLeafMask)
+            return false;
+        hit = HitAABB(eyeRay, s.inodes[idx].aabb);
+        return true;
+    };
+    hitNode(0);
+    if (hit.tEnter > hit.tExit)
+        return {0, 0, 0, 0};
+    constexpr float EnterAlpha = .7f;
+    constexpr float ExitAlpha = 1.f - EnterAlpha;
+    vec3 color = V3(-1.f);
+    if (displayTreeHeight == 0) {
+        vec3 enterPos = eyeRay.pos + hit.tEnter * eyeRay.dir - rootAABB.minPos;
+        vec3 exitPos = eyeRay.pos + hit.tExit * eyeRay.dir - rootAABB.minPos;
+        color = (EnterAlpha * enterPos + ExitAlpha * exitPos) / extent;
+        return ToRGBA(color);
+    }
+    uint32_t stkNode[32];
+    uint8_t stkCnt[32];
+    uint8_t sz = 1;
+    stkNode[0] = 0;
+    stkCnt[0] = 0;
+    float tNearest = FloatMax;
+    while (sz != 0) {
+        if (stkCnt[sz - 1] == 2) {
+            --sz;
+            continue;
+        }
+        uint32_t chIdx =
+            stkCnt[sz - 1] == 0 ? s.inodes[stkNode[sz - 1]].lft : s.inodes[stkNode[sz - 1]].rht;
+        ++stkCnt[sz - 1];
+        bool childIsINode = hitNode(chIdx);
+        if (childIsINode && hit.tEnter <= hit.tExit) {
+            if (displayTreeHeight == sz - 1 && hit.tEnter < tNearest) {
+                vec3 minPos = s.inodes[chIdx].aabb.minPos;
+                vec3 ext = s.inodes[chIdx].aabb.maxPos - s.inodes[chIdx].aabb.minPos;
+                for (int a = 0; a < 3; ++a)
+                    if (ext[a] < FloatEps)
+                        ext[a] = FloatEps;
+                vec3 enterPos = eyeRay.pos + hit.tEnter * eyeRay.dir - minPos;
+                vec3 exitPos = eyeRay.pos + hit.tExit * eyeRay.dir - minPos;
+                color = (EnterAlpha * enterPos + ExitAlpha * exitPos) / ext;
+                tNearest = hit.tEnter;
+            } else if (sz <= displayTreeHeight) {
+                stkNode[sz] = chIdx;
+                stkCnt[sz] = 0;
+                ++sz;
+            }
+        }
+    }
+    if (tNearest == FloatMax)
+        return {0, 0, 0, 0};
+    return ToRGBA(color);
+}
+
+// ray_tracer_render.cu:272-310
+RGBA8 renderLights(const Scene &s, const Ray &eyeRay) {
+    vec3 color = V3(0.f);
+    float tNearest = FloatMax;
+    for (uint32_t li = 0; li < s.lightNum; ++li) {
+        const Light &l = s.lights[li];
+        if (l.type == 0) {
+            HitQuadResult h = HitQuad(eyeRay, V(l.quad.o), V(l.quad.u), V(l.quad.v));
+            if (h.t >= 0.f && h.t < tNearest) {
+                color.x = h.u / length(V(l.quad.u));
+                color.y = h.v / length(V(l.quad.v));
+                tNearest = h.t;
+            }
+        } else {
+            HitShell h = HitSphere(eyeRay, l.sphere.rSqr, V(l.sphere.o));
+            if (h.tEnter <= h.tExit && h.tEnter < tNearest) {
+                vec3 dir = eyeRay.pos + h.tEnter * eyeRay.dir - V(l.sphere.o);
+                dir = normalize(dir);
+                color = vabs(dir);
+                tNearest = h.tEnter;
+            }
+        }
+    }
+    if (tNearest == FloatMax)
+        return {0, 0, 0, 0};
+    return ToRGBA(color);
+}
+
+// the four closest-hit targets, ray_tracer_render.cu:508-551
+RGBA8 renderHitTarget(const Scene &s, const AABB &rootAABB, int target, const Ray &eyeRay) {
+    Nearest n = rayCastLBVH(s, eyeRay);
+    if (n.t == FloatMax)
+        return {0, 0, 0, 0};
+    vec3 color = V3(0.f);
+    const float bx = n.bary.x, by = n.bary.y;
+    if (target == 2) { // Triangles
+        color = {bx, by, 1.f - bx - by};
+    } else if (target == 4) { // Positions
+        vec3 pos = eyeRay.pos + n.t * eyeRay.dir;
+        color = (pos - rootAABB.minPos) / (rootAABB.maxPos - rootAABB.minPos);
+    } else if (target == 5) { // Normals: norms[0] is used for both of the first two weights (:537)
+        const Triangle &f = s.triangles[n.fi];
+        vec3 n0 = LoadV3(s.normals, f.normIdx[0]), n2 = LoadV3(s.normals, f.normIdx[2]);
+        color = vabs(bx * n0 + by * n0 + (1.f - bx - by) * n2);
+    } else { // TextureCoords: reads the NORMALS array with the texture-coordinate indices (:547-551)
+        const Triangle &f = s.triangles[n.fi];
+        vec3 a = LoadV3(s.normals, f.texCoordIdx[0]), c = LoadV3(s.normals, f.texCoordIdx[2]);
+        vec2 n0 = {a.x, a.y}, n2 = {c.x, c.y};
+        float w = 1.f - bx - by;
+        color.x = std::fabs(bx * n0.x + by * n0.x + w * n2.x);
+        color.y = std::fabs(bx * n0.y + by * n0.y + w * n2.y);
+    }
+    return ToRGBA(color);
+}
+
 } // namespace
 
 extern "C" {
@@ -376,6 +550,62 @@ void ko_pt_render_sample(const ko_pt_scene *sc, float *accum, uint8_t *rgba, int
             rgba[4 * idx + 1] = static_cast<uint8_t>(255.f * color.y);
             rgba[4 * idx + 2] = static_cast<uint8_t>(255.f * color.z);
             rgba[4 * idx + 3] = 255;
+        }
+}
+
+// One Render call of ray_tracer_render.cu:461-558 for a target other than Scene, rows [y0, y1).
+// target: 1 AABBs, 2 Triangles, 3 Lights, 4 Positions, 5 Normals, 6 TextureCoords (the order of
+// RayTracer::RenderTarget). rootAABB = LBVH::DeviceData::rootAABB (6 floats).
+void ko_rt_render_target(const ko_pt_scene *sc, const float *rootAABB6, int displayTreeHeight,
+                         int target, uint8_t *rgba, int W, int H, int y0, int y1) {
+    Scene s;
+    s.inodes = static_cast<const InternalNode *>(sc->inodes);
+    s.faces = sc->faces;
+    s.compactedFaces = sc->compactedFaces;
+    s.faceNum = sc->faceNum;
+    s.compactedFaceNum = sc->compactedFaceNum;
+    s.positions = sc->positions;
+    s.facePosIdx = sc->facePosIdx;
+    s.normals = sc->normals;
+    s.triangles = static_cast<const Triangle *>(sc->triangles);
+    s.materials = static_cast<const Material *>(sc->materials);
+    s.lights = static_cast<const Light *>(sc->lights);
+    s.lightNum = sc->lightNum;
+    s.lightTotArea = sc->lightTotArea;
+    s.maxPathDepth = static_cast<uint8_t>(sc->maxPathDepth);
+    AABB root{{rootAABB6[0], rootAABB6[1], rootAABB6[2]}, {rootAABB6[3], rootAABB6[4], rootAABB6[5]}};
+    mat4 w2s, invProj;
+    mat3 rot;
+    std::memcpy(&w2s, sc->w2s, 64);
+    std::memcpy(&invProj, sc->invProj, 64);
+    std::memcpy(&rot, sc->eyeRot, 36);
+    vec3 eyePos = V(sc->eyePos);
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int y = y0; y < y1; ++y)
+        for (int x = 0; x < W; ++x) {
+            Ray eyeRay;
+            vec4 tmp;
+            tmp.z = static_cast<float>(W);
+            tmp.w = static_cast<float>(H);
+            tmp.x = (2.f * x + 1.f - tmp.z) / tmp.z;
+            tmp.y = (2.f * y + 1.f - tmp.w) / tmp.w;
+            tmp.z = 1.f;
+            tmp.w = 1.f;
+            tmp = invProj * tmp;
+            eyeRay.dir = {tmp.x, tmp.y, tmp.z};
+            eyeRay.dir = rot * normalize(eyeRay.dir);
+            eyeRay.dir = normalize(eyeRay.dir); // the w2s-transformed temporary is discarded (:487-489)
+            vec4 p = w2s * vec4{eyePos.x, eyePos.y, eyePos.z, 1.f};
+            eyeRay.pos = {p.x, p.y, p.z};
+            RGBA8 c;
+            if (target == 1)
+                c = renderAABB(s, root, static_cast<uint8_t>(displayTreeHeight), eyeRay);
+            else if (target == 3)
+                c = renderLights(s, eyeRay);
+            else
+                c = renderHitTarget(s, root, target, eyeRay);
+            uint8_t *o = rgba + 4 * (static_cast<size_t>(y) * W + x);
+            o[0] = c.r, o[1] = c.g, o[2] = c.b, o[3] = c.a;
         }
 }
 

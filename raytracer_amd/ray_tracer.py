@@ -259,12 +259,31 @@ class RayTracer:
     def GetCurrentAccumulatedSamplePerPixel(self) -> float:
         return self.curr_accu_spp
 
-    def Render(self, fb: FrameBuffer, rows=None) -> None:
-        """ray_tracer_render.cu:433-647 for RenderTarget::Scene. `rows` = (y0, y1) restricts the call
-        to a stripe of the image (multi-GPU tiling); the sample counter advances all the same."""
+    RENDER_TARGETS = ("Scene", "AABBs", "Triangles", "Lights", "Positions", "Normals", "TextureCoords",
+                      "None")
+
+    def Render(self, fb: FrameBuffer, rows=None, target: str = "Scene") -> None:
+        """ray_tracer_render.cu:433-647. `target` is one of RENDER_TARGETS (RayTracer::RenderTarget);
+        "Scene" path-traces and accumulates one sample, the others draw one inspection frame. `rows` =
+        (y0, y1) restricts the call to a stripe of the image (multi-GPU tiling); the sample counter
+        advances all the same."""
         import sys
         if self.lbvh is None or not self.lbvh.IsComplete():
             print(f"{self.ErrTag} lbvh is not set.", file=sys.stderr)
+            return
+        if target not in self.RENDER_TARGETS:
+            raise ValueError(f"unknown render target {target!r}")
+        if target == "None":
+            return
+        if target != "Scene":
+            y0, y1 = rows if rows is not None else (0, fb.height)
+            with torch.cuda.device(self.device):
+                _lib.check(_lib.lib().kk_rt_render_target(
+                    self.lbvh.GetDeivceDataDevicePtr(), C.byref(self._scene), C.byref(self._frame),
+                    self.RENDER_TARGETS.index(target), fb.rgba.data_ptr(), fb.width, fb.height, int(y0),
+                    int(y1), _lib.current_stream_ptr()), "kk_rt_render_target")
+            # like the reference, a switch of target restarts the accumulation of the next Scene call
+            self._modified = True
             return
         size = (fb.width, fb.height)
         need_redraw = self._modified

@@ -83,3 +83,28 @@ def test_camera_matches_reference_glm(oracle):
         s = np.array(sc, np.float32)
         ref.kkref_w2s_from_scales(vp(s), vp(out))
         assert np.array_equal(cam.world_to_scene(s).reshape(-1), out)
+
+
+def test_inspection_targets_on_cpu(oracle, veach):
+    """The checker's inspection targets: the Triangles target is opaque exactly where the closest-hit
+    search finds a triangle, its colour is the barycentric triple, and the AABBs target at height 0
+    covers the root box."""
+    from raytracer_amd.data import camera as cam
+    from scene_util import veach_arrays, veach_camera
+    W, H = 64, 48
+    arr = veach_arrays(veach)
+    c, proj = veach_camera(veach, W, H)
+    b = oracle.lbvh_build(veach["positions"], veach["face_position_indices"])
+    args = (b, arr, np.eye(4, dtype=np.float32), cam.inverse_projective(proj), c.pos, c.rotation(), W, H)
+    tri = oracle.rt_render_target(*args, "Triangles")
+    box = oracle.rt_render_target(*args, "AABBs", display_tree_height=0)
+    hit = tri[..., 3] == 255
+    assert 0.3 < hit.mean() < 1.0
+    assert (box[..., 3][hit] == 255).all()          # a hit triangle lies inside the root box
+    s = tri[..., :3].astype(int).sum(axis=2)[hit]
+    assert s.min() >= 252 and s.max() <= 255        # u + v + (1 - u - v) = 1 up to truncation
+    pos = oracle.rt_render_target(*args, "Positions")
+    assert (pos[..., 3] == tri[..., 3]).all()
+    rows = oracle.rt_render_target(*args, "Normals", rows=(10, 20))
+    full = oracle.rt_render_target(*args, "Normals")
+    assert (rows[10:20] == full[10:20]).all() and not rows[:10].any()
