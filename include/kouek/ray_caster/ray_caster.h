@@ -1,7 +1,9 @@
 // kouek::RayCaster::RayCaster with the reference's public interface for the Depth-Box VDB path
 // (reference include/ray_caster/ray_caster.h:16-89, src/ray_caster/ray_caster.cu,
 // src/ray_caster/ray_caster_dpbx_vdb.cu:439-532). Surfaces and textures become HIP::FrameBuffer /
-// HIP::TransferFunctionTable. RenderRAWVolume and the debug targets are not implemented.
+// HIP::TransferFunctionTable; the RAW volume is a HIP::Volume<T> (the reference binds an untyped
+// texture, so its SetRAWVolume / RenderRAWVolume take no type; here they are templates on the voxel
+// type). The Depth-Box VDB debug targets are not implemented.
 #ifndef KOUEK_RAY_CASTER_RAY_CASTER_H
 #define KOUEK_RAY_CASTER_RAY_CASTER_H
 
@@ -19,12 +21,24 @@ class RayCaster : Noncopyable {
     kk_dvr_frame rndrParamPerFrame{};
     std::shared_ptr<HIP::TransferFunctionTable> tfTex;
     std::shared_ptr<DepthBoxVDB> vdb;
+    std::shared_ptr<const void> volTex; // HIP::Volume<T>, type-erased
+    const void *volDat = nullptr;
+    uint32_t volDim[3] = {0, 0, 0};
+    size_t volVoxelBytes = 0;
     static constexpr std::string_view ErrTag = "[RayCaster Error]";
 
   public:
     RayCaster() {
         rndrParam.max_alpha = .9f;
         rndrParam.sampling_rate = 3.f;
+    }
+    template <typename T> void SetRAWVolume(std::shared_ptr<HIP::Volume<T>> vol) {
+        static_assert(sizeof(T) == 1 || sizeof(T) == 2, "uint8_t or uint16_t voxels");
+        volTex = vol;
+        volDat = vol ? vol->Get() : nullptr;
+        volVoxelBytes = sizeof(T);
+        for (int i = 0; i < 3; ++i)
+            volDim[i] = vol ? vol->GetDimension()[i] : 0;
     }
     void SetDepthBoxVDB(std::shared_ptr<DepthBoxVDB> vdb) { this->vdb = vdb; }
     void SetMaximumAlpha(float maxAlpha) { rndrParam.max_alpha = maxAlpha; }
@@ -51,6 +65,27 @@ class RayCaster : Noncopyable {
         std::memcpy(rndrParam.light_col, &in.lightCol[0], 12);
     }
     void UnsetShading() { rndrParam.use_shading = 0; }
+
+    enum class RAWVolumeRenderTarget { Scene, AABB };
+    // src/ray_caster/ray_caster_raw_volume.cu:147-246
+    void RenderRAWVolume(HIP::FrameBuffer &rndrTo, const ivec2 &rndrSz,
+                         RAWVolumeRenderTarget rndrTarget = RAWVolumeRenderTarget::Scene) {
+        if (!volDat || !tfTex) {
+            std::cerr << ErrTag << " at " << __FILE__ << ":" << __LINE__ << ". volTex or tfTex are not set.\n";
+            return;
+        }
+        const int target = rndrTarget == RAWVolumeRenderTarget::Scene ? KK_RAW_TARGET_SCENE : KK_RAW_TARGET_AABB;
+        if (volVoxelBytes == 1)
+            KOUEK_HIP_CHECK(ErrTag.data(),
+                            kk_raw_render_u8(static_cast<const uint8_t *>(volDat), volDim[0], volDim[1],
+                                             volDim[2], tfTex->Get(), &rndrParam, &rndrParamPerFrame, target,
+                                             rndrTo.Get(), rndrSz.x, rndrSz.y, 0, rndrSz.y, nullptr, nullptr));
+        else
+            KOUEK_HIP_CHECK(ErrTag.data(),
+                            kk_raw_render_u16(static_cast<const uint16_t *>(volDat), volDim[0], volDim[1],
+                                              volDim[2], tfTex->Get(), &rndrParam, &rndrParamPerFrame, target,
+                                              rndrTo.Get(), rndrSz.x, rndrSz.y, 0, rndrSz.y, nullptr, nullptr));
+    }
 
     enum class DPBXVDBRenderTarget { Scene, AABBs, Depths, PositionsAfterDepthSkip };
     template <typename T>

@@ -403,6 +403,22 @@ int kk_dvr_render_stripes_u16(const kk_vdb_device_data *h_vdb, const float *d_tf
                               uint8_t *d_rgba, int width, int height, int stripe_first,
                               int stripe_stride, unsigned long long *d_counters, void *stream);
 
+/* ================================================================================================
+ * Path 2c: RAW-volume ray caster  --  kouek::RayCaster::RayCaster::RenderRAWVolume
+ *          (src/ray_caster/ray_caster_raw_volume.cu:27-246): the same compositing over the dense volume,
+ *          no empty-space skipping. d_volume is T[dz][dy][dx]; samples are fp32 trilinear reads with
+ *          0 outside the volume. d_counters (optional, uint64[1]) accumulates the samples taken.
+ * ============================================================================================== */
+enum { KK_RAW_TARGET_SCENE = 0, KK_RAW_TARGET_AABB = 1 }; /* RayCaster::RAWVolumeRenderTarget */
+int kk_raw_render_u8(const uint8_t *d_volume, uint32_t dx, uint32_t dy, uint32_t dz, const float *d_tf,
+                     const kk_dvr_params *h_params, const kk_dvr_frame *h_frame, int target,
+                     uint8_t *d_rgba, int width, int height, int y0, int y1,
+                     unsigned long long *d_counters, void *stream);
+int kk_raw_render_u16(const uint16_t *d_volume, uint32_t dx, uint32_t dy, uint32_t dz, const float *d_tf,
+                      const kk_dvr_params *h_params, const kk_dvr_frame *h_frame, int target,
+                      uint8_t *d_rgba, int width, int height, int y0, int y1,
+                      unsigned long long *d_counters, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

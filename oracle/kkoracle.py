@@ -299,6 +299,40 @@ class _KoDvrParams(C.Structure):
                 ("shiness", C.c_float), ("lightPos", C.c_float * 3), ("lightCol", C.c_float * 3)]
 
 
+def _dvr_params(w2s, inv_proj, eye_pos, eye_rot, max_alpha, sampling_rate, shading):
+    pr = _KoDvrParams()
+    for name, val in (("w2s", w2s), ("invProj", inv_proj), ("eyePos", eye_pos), ("eyeRot", eye_rot)):
+        arr = getattr(pr, name)
+        for i, x in enumerate(np.asarray(val, np.float32).reshape(-1)):
+            arr[i] = float(x)
+    pr.maxAlpha, pr.samplingRate = max_alpha, sampling_rate
+    pr.useShading = 0
+    if shading is not None:
+        pr.useShading = 1
+        pr.ka, pr.kd, pr.ks, pr.shiness = (shading[k] for k in ("ka", "kd", "ks", "shiness"))
+        for i in range(3):
+            pr.lightPos[i] = float(shading["lightPosInVolumeSpace"][i])
+            pr.lightCol[i] = float(shading["lightCol"][i])
+    return pr
+
+
+def raw_render(volume: np.ndarray, tf: np.ndarray, w2s, inv_proj, eye_pos, eye_rot, W: int, H: int,
+               max_alpha=0.9, sampling_rate=3.0, shading=None, rows=None, target: str = "Scene"):
+    """One RenderRAWVolume frame on the CPU (target "Scene" or "AABB") -> (rgba [H,W,4] u8, samples)."""
+    vol = np.ascontiguousarray(volume)
+    assert vol.dtype in (np.uint8, np.uint16) and vol.ndim == 3
+    dz, dy, dx = vol.shape
+    pr = _dvr_params(w2s, inv_proj, eye_pos, eye_rot, max_alpha, sampling_rate, shading)
+    tf = np.ascontiguousarray(tf, np.float32).reshape(256, 4)
+    rgba = np.zeros((H, W, 4), np.uint8)
+    y0, y1 = rows if rows is not None else (0, H)
+    samples = C.c_uint64(0)
+    lib().ko_raw_render(_vp(vol), C.c_int(int(vol.dtype == np.uint16)), C.c_int(dx), C.c_int(dy),
+                        C.c_int(dz), _vp(tf), C.byref(pr), C.c_int(("Scene", "AABB").index(target)),
+                        _vp(rgba), C.c_int(W), C.c_int(H), C.c_int(y0), C.c_int(y1), C.byref(samples))
+    return rgba, int(samples.value)
+
+
 def dvr_render(vdb: OracleVDB, tf: np.ndarray, w2s, inv_proj, eye_pos, eye_rot, W: int, H: int,
                max_alpha=0.9, sampling_rate=3.0, shading=None, rows=None, rgba=None):
     """One RenderDepthBoxVDB(Scene) frame on the CPU -> (rgba [H,W,4] u8, number of samples taken)."""

@@ -1,7 +1,8 @@
 // TEST INFRASTRUCTURE ONLY (see ko_math.h). CPU restatement of the Depth-Box VDB ray marcher:
 // RayCaster::RenderDepthBoxVDB<T> for the Scene target
 // (src/ray_caster/ray_caster_dpbx_vdb.cu:44-282, 465-531) with VDBStack, HDDA3D and DepthDDA2D of
-// include/ray_caster/dda.h.
+// include/ray_caster/dda.h, and of the un-accelerated RayCaster::RenderRAWVolume
+// (src/ray_caster/ray_caster_raw_volume.cu:27-246).
 //
 // Texture hardware is restated in software, with these stated conventions (CUDA's filtering weights
 // are quantised to 8 fractional bits, which nothing here can reproduce or check: "sub-1/256
@@ -416,6 +417,168 @@ void renderDVR(const VDB<T> &vdb, const float *tf, const RenderParam &rp, uint8_
         *samplesOut = total;
 }
 
+// ---- RayCaster::RenderRAWVolume (src/ray_caster/ray_caster_raw_volume.cu:27-246) ---------------------
+// volTex: linear, non-normalised coordinates, border addressing, normalised-float read
+// (include/cuda/texture.h:93-98), restated like atlasTex above with 0 outside the volume.
+template <typename T> struct RawVolume {
+    const T *vol;
+    int dx, dy, dz;
+    const float *tf;
+    float maxT;
+    uint64_t samples = 0;
+
+    float linear(vec3 sp) const {
+        vec3 b = sp - .5f;
+        vec3 f = {std::floor(b.x), std::floor(b.y), std::floor(b.z)};
+        int i = static_cast<int>(f.x), j = static_cast<int>(f.y), k = static_cast<int>(f.z);
+        float ax = b.x - f.x, ay = b.y - f.y, az = b.z - f.z;
+        float v[2][2][2];
+        for (int zz = 0; zz < 2; ++zz)
+            for (int yy = 0; yy < 2; ++yy)
+                for (int xx = 0; xx < 2; ++xx) {
+                    int x = i + xx, y = j + yy, z = k + zz;
+                    T t = 0;
+                    if (x >= 0 && y >= 0 && z >= 0 && x < dx && y < dy && z < dz)
+                        t = vol[(static_cast<size_t>(z) * dy + y) * dx + x];
+                    v[zz][yy][xx] = static_cast<float>(t) / maxT;
+                }
+        float c00 = (1.f - ax) * v[0][0][0] + ax * v[0][0][1];
+        float c01 = (1.f - ax) * v[0][1][0] + ax * v[0][1][1];
+        float c10 = (1.f - ax) * v[1][0][0] + ax * v[1][0][1];
+        float c11 = (1.f - ax) * v[1][1][0] + ax * v[1][1][1];
+        float c0 = (1.f - ay) * c00 + ay * c01;
+        float c1 = (1.f - ay) * c10 + ay * c11;
+        return (1.f - az) * c0 + az * c1;
+    }
+    vec4 tfLinear(float u) const {
+        float x = u * 256.f - .5f;
+        float fl = std::floor(x);
+        int i = static_cast<int>(fl);
+        float a = x - fl;
+        vec4 t0 = {0, 0, 0, 0}, t1 = {0, 0, 0, 0};
+        if (i >= 0 && i <= 255)
+            t0 = {tf[4 * i], tf[4 * i + 1], tf[4 * i + 2], tf[4 * i + 3]};
+        if (i + 1 >= 0 && i + 1 <= 255)
+            t1 = {tf[4 * i + 4], tf[4 * i + 5], tf[4 * i + 6], tf[4 * i + 7]};
+        return (1.f - a) * t0 + a * t1;
+    }
+
+    // renderScene<UseShading>, :27-129, and renderAABB, :131-145
+    void render(const RenderParam &rp, int target, Ray eyeRay, uint8_t out[4]) {
+        out[0] = out[1] = out[2] = out[3] = 0;
+        HitShell hit = HitAABB(eyeRay, AABB{{0.f, 0.f, 0.f}, {1.f, 1.f, 1.f}});
+        if (hit.tEnter > hit.tExit)
+            return;
+        if (target == 1) {
+            vec3 enterPos = eyeRay.pos + hit.tEnter * eyeRay.dir;
+            vec3 exitPos = eyeRay.pos + hit.tExit * eyeRay.dir;
+            vec3 color = .3f * enterPos + .7f * exitPos;
+            out[0] = static_cast<uint8_t>(255.f * color.x);
+            out[1] = static_cast<uint8_t>(255.f * color.y);
+            out[2] = static_cast<uint8_t>(255.f * color.z);
+            out[3] = 255;
+            return;
+        }
+        const vec3 dim = {static_cast<float>(dx), static_cast<float>(dy), static_cast<float>(dz)};
+        uint32_t stepCnt = 0;
+        vec3 d0 = (hit.tExit - hit.tEnter) * eyeRay.dir;
+        uint32_t maxStepCnt = static_cast<uint32_t>(
+            std::ceil(rp.samplingRate * length(d0) * gmax(dim.x, gmax(dim.y, dim.z))));
+        eyeRay.pos = eyeRay.pos * dim;
+        eyeRay.dir = normalize(eyeRay.dir * dim);
+        hit = HitAABB(eyeRay, AABB{{0.f, 0.f, 0.f}, dim});
+        if (hit.tEnter > hit.tExit)
+            return;
+        float step = (hit.tExit - hit.tEnter) / (maxStepCnt - 1);
+        auto inBox = [&]() {
+            for (int k = 0; k < 3; ++k)
+                if (eyeRay.pos[k] < 0.f || eyeRay.pos[k] >= dim[k])
+                    return false;
+            return true;
+        };
+        hit.tEnter = step * std::ceil(hit.tEnter / step);
+        eyeRay.pos += hit.tEnter * eyeRay.dir;
+        if (!inBox())
+            eyeRay.pos += step * eyeRay.dir;
+        vec3 rgb = {0.f, 0.f, 0.f};
+        float a = 0.f;
+        while (stepCnt <= maxStepCnt && inBox()) {
+            float scalar = linear(eyeRay.pos);
+            vec4 tfCol = tfLinear(scalar);
+            vec3 tfColRGB = {tfCol.x, tfCol.y, tfCol.z};
+            ++samples;
+            if (rp.useShading) {
+                vec3 N;
+                vec3 sp = eyeRay.pos;
+                for (int k = 0; k < 3; ++k) {
+                    sp[k] += .5f;
+                    float v0 = linear(sp);
+                    sp[k] -= 1.f;
+                    float v1 = linear(sp);
+                    N[k] = v1 - v0;
+                }
+                N = normalize(N);
+                if (dot(eyeRay.dir, N) > 0.f)
+                    N = -N;
+                vec3 p2lDir = normalize(rp.lightPos - eyeRay.pos);
+                vec3 ambient = rp.ka * tfColRGB;
+                vec3 diffuse = rp.kd * gmax(0.f, dot(N, p2lDir)) * tfColRGB * rp.lightCol;
+                vec3 hfDir = normalize(p2lDir - eyeRay.dir);
+                vec3 specular = rp.ks * std::pow(gmax(0.f, dot(N, hfDir)), rp.shiness) * rp.lightCol;
+                for (int k = 0; k < 3; ++k)
+                    tfColRGB[k] = ambient[k] + diffuse[k] + specular[k];
+            }
+            rgb = rgb + (1.f - a) * tfCol.w * tfColRGB;
+            a = a + (1.f - a) * tfCol.w;
+            if (a >= rp.maxAlpha)
+                break;
+            ++stepCnt;
+            eyeRay.pos += step * eyeRay.dir;
+        }
+        rgb = rgb / (rgb + 1.f);
+        for (int k = 0; k < 3; ++k)
+            rgb[k] = std::pow(rgb[k], 1.f / 2.2f);
+        out[0] = static_cast<uint8_t>(255.f * rgb.x);
+        out[1] = static_cast<uint8_t>(255.f * rgb.y);
+        out[2] = static_cast<uint8_t>(255.f * rgb.z);
+        out[3] = static_cast<uint8_t>(255.f * a);
+    }
+};
+
+template <typename T>
+void renderRAW(const T *vol, int dx, int dy, int dz, const float *tf, const RenderParam &rp, int target,
+               uint8_t *rgba, int W, int H, int y0, int y1, uint64_t *samplesOut) {
+    uint64_t total = 0;
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : total)
+    for (int y = y0; y < y1; ++y) {
+        RawVolume<T> rv{vol, dx, dy, dz, tf, sizeof(T) == 1 ? 255.f : 65535.f};
+        for (int x = 0; x < W; ++x) {
+            Ray eyeRay;
+            vec4 tmp;
+            tmp.z = static_cast<float>(W);
+            tmp.w = static_cast<float>(H);
+            tmp.x = (2.f * x + 1.f - tmp.z) / tmp.z;
+            tmp.y = (2.f * y + 1.f - tmp.w) / tmp.w;
+            tmp.z = 1.f;
+            tmp.w = 1.f;
+            tmp = rp.invProj * tmp;
+            eyeRay.dir = {tmp.x, tmp.y, tmp.z};
+            eyeRay.dir = rp.eyeRot * normalize(eyeRay.dir);
+            tmp = {eyeRay.dir.x, eyeRay.dir.y, eyeRay.dir.z, 0.f};
+            tmp = rp.w2s * tmp;
+            eyeRay.dir = {tmp.x, tmp.y, tmp.z};
+            eyeRay.dir = normalize(eyeRay.dir);
+            tmp = {rp.eyePos.x, rp.eyePos.y, rp.eyePos.z, 1.f};
+            tmp = rp.w2s * tmp;
+            eyeRay.pos = {tmp.x, tmp.y, tmp.z};
+            rv.render(rp, target, eyeRay, rgba + 4 * (static_cast<size_t>(y) * W + x));
+        }
+        total += rv.samples;
+    }
+    if (samplesOut)
+        *samplesOut = total;
+}
+
 } // namespace
 
 extern "C" {
@@ -450,6 +613,32 @@ void ko_dvr_render(const void *vdbHandle, int is16, const float *tf256x4, const 
                   samplesOut);
     else
         renderDVR(*static_cast<const VDB<uint8_t> *>(vdbHandle), tf256x4, rp, rgba, W, H, y0, y1,
+                  samplesOut);
+}
+
+// RenderRAWVolume over the dense volume T[dz][dy][dx]; target 0 = Scene, 1 = AABB.
+void ko_raw_render(const void *vol, int is16, int dx, int dy, int dz, const float *tf256x4,
+                   const ko_dvr_params *pr, int target, uint8_t *rgba, int W, int H, int y0, int y1,
+                   uint64_t *samplesOut) {
+    RenderParam rp;
+    std::memcpy(&rp.w2s, pr->w2s, 64);
+    std::memcpy(&rp.invProj, pr->invProj, 64);
+    rp.eyePos = {pr->eyePos[0], pr->eyePos[1], pr->eyePos[2]};
+    std::memcpy(&rp.eyeRot, pr->eyeRot, 36);
+    rp.maxAlpha = pr->maxAlpha;
+    rp.samplingRate = pr->samplingRate;
+    rp.useShading = pr->useShading != 0;
+    rp.ka = pr->ka;
+    rp.kd = pr->kd;
+    rp.ks = pr->ks;
+    rp.shiness = pr->shiness;
+    rp.lightPos = {pr->lightPos[0], pr->lightPos[1], pr->lightPos[2]};
+    rp.lightCol = {pr->lightCol[0], pr->lightCol[1], pr->lightCol[2]};
+    if (is16)
+        renderRAW(static_cast<const uint16_t *>(vol), dx, dy, dz, tf256x4, rp, target, rgba, W, H, y0, y1,
+                  samplesOut);
+    else
+        renderRAW(static_cast<const uint8_t *>(vol), dx, dy, dz, tf256x4, rp, target, rgba, W, H, y0, y1,
                   samplesOut);
 }
 

@@ -104,6 +104,7 @@ def _declare(l):
         getattr(l, f"kk_vdb_classify_{sfx}").argtypes = [vp, u32, u32, u32, u32, vp, u32, vp, vp]
         getattr(l, f"kk_vdb_fill_atlas_{sfx}").argtypes = [vp, u32, u32, u32, vp, vp, vp, u32, vp, vp]
         getattr(l, f"kk_dvr_render_{sfx}").argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]
+        getattr(l, f"kk_raw_render_{sfx}").argtypes = [vp, u32, u32, u32, vp, vp, vp, i32, vp, i32, i32, i32, i32, vp, vp]
         getattr(l, f"kk_dvr_render_stripes_{sfx}").argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]
     l.kk_vdb_plan_build.argtypes = [u32, u32, u32, vp, C.c_uint8, i32, vp, vp]
     l.kk_vdb_wire.argtypes = [vp, vp, vp, vp, vp]

@@ -453,6 +453,199 @@ __global__ __launch_bounds__(THREADS) void dvr_kernel(const kk_vdb_device_data v
     }
 }
 
+// ---- RayCaster::RenderRAWVolume (src/ray_caster/ray_caster_raw_volume.cu:27-246) --------------------
+// The un-accelerated marcher over the dense volume: every sample is a trilinear read of the raw
+// volume (voxel outside the volume = 0, as the border address mode gives), same transfer function,
+// shading and compositing as above. Target AABB draws the entry / exit points of the unit box.
+
+template <typename T>
+KK_D float sampleVolume(const T *__restrict__ vol, int dx, int dy, int dz, f3 sp) {
+    const f3 b = sp - .5f;
+    const f3 fl = vfloor(b);
+    const float ax = b.x - fl.x, ay = b.y - fl.y, az = b.z - fl.z;
+    const int i = static_cast<int>(fl.x), j = static_cast<int>(fl.y), k = static_cast<int>(fl.z);
+    constexpr float m = MaxOf<T>::value;
+    float v[2][2][2];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int x = i + (c & 1), y = j + ((c >> 1) & 1), z = k + (c >> 2);
+        T t = 0;
+        if (x >= 0 && y >= 0 && z >= 0 && x < dx && y < dy && z < dz)
+            t = vol[(static_cast<size_t>(z) * dy + y) * dx + x];
+        v[c >> 2][(c >> 1) & 1][c & 1] = static_cast<float>(t) / m;
+    }
+    const float c00 = (1.f - ax) * v[0][0][0] + ax * v[0][0][1];
+    const float c01 = (1.f - ax) * v[0][1][0] + ax * v[0][1][1];
+    const float c10 = (1.f - ax) * v[1][0][0] + ax * v[1][0][1];
+    const float c11 = (1.f - ax) * v[1][1][0] + ax * v[1][1][1];
+    const float c0 = (1.f - ay) * c00 + ay * c01;
+    const float c1 = (1.f - ay) * c10 + ay * c11;
+    return (1.f - az) * c0 + az * c1;
+}
+
+template <typename T, bool COUNT>
+__global__ __launch_bounds__(THREADS) void raw_kernel(const T *__restrict__ vol, int dx, int dy, int dz,
+                                                      const float *__restrict__ tf,
+                                                      const kk_dvr_params rp, const kk_dvr_frame fr,
+                                                      int target, uint8_t *__restrict__ rgba, int W,
+                                                      int H, int y0, int y1,
+                                                      unsigned long long *counters) {
+    __shared__ f4 s_tf[256];
+    const int tid = threadIdx.x;
+    s_tf[tid] = reinterpret_cast<const f4 *>(tf)[tid];
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6;
+    const int x = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
+    const int y = y0 + static_cast<int>(blockIdx.y) * 16 + (wave >> 1) * 8 + (lane >> 3);
+    unsigned long long nSamples = 0;
+    if (x < W && y < y1) {
+        Ray eyeRay;
+        {
+            m4 invProj, w2s;
+            m3 rot;
+            for (int c = 0; c < 4; ++c) {
+                invProj.c[c] = {rp.inv_proj[4 * c], rp.inv_proj[4 * c + 1], rp.inv_proj[4 * c + 2],
+                                rp.inv_proj[4 * c + 3]};
+                w2s.c[c] = {rp.w2s[4 * c], rp.w2s[4 * c + 1], rp.w2s[4 * c + 2], rp.w2s[4 * c + 3]};
+            }
+            for (int c = 0; c < 3; ++c)
+                rot.c[c] = {fr.eye_rot[3 * c], fr.eye_rot[3 * c + 1], fr.eye_rot[3 * c + 2]};
+            f4 tmp;
+            tmp.z = static_cast<float>(W);
+            tmp.w = static_cast<float>(H);
+            tmp.x = (2.f * x + 1.f - tmp.z) / tmp.z;
+            tmp.y = (2.f * y + 1.f - tmp.w) / tmp.w;
+            tmp.z = 1.f;
+            tmp.w = 1.f;
+            tmp = invProj * tmp;
+            eyeRay.dir = {tmp.x, tmp.y, tmp.z};
+            eyeRay.dir = rot * normalize(eyeRay.dir);
+            tmp = {eyeRay.dir.x, eyeRay.dir.y, eyeRay.dir.z, 0.f};
+            tmp = w2s * tmp;
+            eyeRay.dir = normalize(F3(tmp.x, tmp.y, tmp.z));
+            tmp = w2s * f4{fr.eye_pos[0], fr.eye_pos[1], fr.eye_pos[2], 1.f};
+            eyeRay.pos = {tmp.x, tmp.y, tmp.z};
+        }
+        uchar4 o = make_uchar4(0, 0, 0, 0);
+        float tEnter, tExit;
+        HitAABB(eyeRay, AABB{F3(0.f), F3(1.f)}, tEnter, tExit);
+        if (!(tEnter > tExit)) {
+            if (target == KK_RAW_TARGET_AABB) {
+                // renderAABB, ray_caster_raw_volume.cu:131-145
+                const f3 enterPos = eyeRay.pos + tEnter * eyeRay.dir;
+                const f3 exitPos = eyeRay.pos + tExit * eyeRay.dir;
+                const f3 color = .3f * enterPos + .7f * exitPos;
+                o = make_uchar4(static_cast<uint8_t>(255.f * color.x), static_cast<uint8_t>(255.f * color.y),
+                                static_cast<uint8_t>(255.f * color.z), 255);
+            } else {
+                const f3 dim = {static_cast<float>(dx), static_cast<float>(dy), static_cast<float>(dz)};
+                uint32_t stepCnt = 0;
+                const f3 d0 = (tExit - tEnter) * eyeRay.dir;
+                // the reference keeps the rounded-up float in a uint32_t
+                const uint32_t maxStepCnt = static_cast<uint32_t>(
+                    ceilf(rp.sampling_rate * length(d0) * gmax(dim.x, gmax(dim.y, dim.z))));
+                eyeRay.pos = eyeRay.pos * dim;
+                eyeRay.dir = normalize(eyeRay.dir * dim);
+                HitAABB(eyeRay, AABB{F3(0.f), dim}, tEnter, tExit);
+                if (!(tEnter > tExit)) {
+                    const float step = (tExit - tEnter) / (maxStepCnt - 1);
+                    auto inBox = [&]() {
+                        return !(eyeRay.pos.x < 0.f || eyeRay.pos.x >= dim.x || eyeRay.pos.y < 0.f ||
+                                 eyeRay.pos.y >= dim.y || eyeRay.pos.z < 0.f || eyeRay.pos.z >= dim.z);
+                    };
+                    tEnter = step * ceilf(tEnter / step);
+                    eyeRay.pos = eyeRay.pos + tEnter * eyeRay.dir;
+                    if (!inBox())
+                        eyeRay.pos = eyeRay.pos + step * eyeRay.dir;
+                    f3 rgb = {0.f, 0.f, 0.f};
+                    float a = 0.f;
+                    while (stepCnt <= maxStepCnt && inBox()) {
+                        const float scalar = sampleVolume<T>(vol, dx, dy, dz, eyeRay.pos);
+                        const f4 tfCol = tfLookup(s_tf, scalar);
+                        f3 tfColRGB = {tfCol.x, tfCol.y, tfCol.z};
+                        if (COUNT)
+                            ++nSamples;
+                        if (rp.use_shading) {
+                            f3 N;
+                            f3 sp = eyeRay.pos;
+                            sp.x += .5f;
+                            float v0 = sampleVolume<T>(vol, dx, dy, dz, sp);
+                            sp.x -= 1.f;
+                            float v1 = sampleVolume<T>(vol, dx, dy, dz, sp);
+                            N.x = v1 - v0;
+                            sp.y += .5f;
+                            v0 = sampleVolume<T>(vol, dx, dy, dz, sp);
+                            sp.y -= 1.f;
+                            v1 = sampleVolume<T>(vol, dx, dy, dz, sp);
+                            N.y = v1 - v0;
+                            sp.z += .5f;
+                            v0 = sampleVolume<T>(vol, dx, dy, dz, sp);
+                            sp.z -= 1.f;
+                            v1 = sampleVolume<T>(vol, dx, dy, dz, sp);
+                            N.z = v1 - v0;
+                            N = normalize(N);
+                            if (dot(eyeRay.dir, N) > 0.f)
+                                N = -N;
+                            const f3 lightPos = {rp.light_pos[0], rp.light_pos[1], rp.light_pos[2]};
+                            const f3 lightCol = {rp.light_col[0], rp.light_col[1], rp.light_col[2]};
+                            const f3 p2lDir = normalize(lightPos - eyeRay.pos);
+                            const f3 ambient = rp.ka * tfColRGB;
+                            const f3 diffuse = rp.kd * gmax(0.f, dot(N, p2lDir)) * tfColRGB * lightCol;
+                            const f3 hfDir = normalize(p2lDir - eyeRay.dir);
+                            const f3 specular = rp.ks * powf(gmax(0.f, dot(N, hfDir)), rp.shiness) * lightCol;
+                            tfColRGB = {ambient.x + diffuse.x + specular.x, ambient.y + diffuse.y + specular.y,
+                                        ambient.z + diffuse.z + specular.z};
+                        }
+                        rgb = rgb + (1.f - a) * tfCol.w * tfColRGB;
+                        a = a + (1.f - a) * tfCol.w;
+                        if (a >= rp.max_alpha)
+                            break;
+                        ++stepCnt;
+                        eyeRay.pos = eyeRay.pos + step * eyeRay.dir;
+                    }
+                    rgb = rgb / (rgb + 1.f);
+                    rgb.x = powf(rgb.x, 1.f / 2.2f);
+                    rgb.y = powf(rgb.y, 1.f / 2.2f);
+                    rgb.z = powf(rgb.z, 1.f / 2.2f);
+                    o = make_uchar4(static_cast<uint8_t>(255.f * rgb.x), static_cast<uint8_t>(255.f * rgb.y),
+                                    static_cast<uint8_t>(255.f * rgb.z), static_cast<uint8_t>(255.f * a));
+                }
+            }
+        }
+        reinterpret_cast<uchar4 *>(rgba)[static_cast<size_t>(y) * W + x] = o;
+    }
+    if (COUNT) {
+        for (int o = 32; o > 0; o >>= 1)
+            nSamples += __shfl_xor(nSamples, o, 64);
+        if (lane == 0)
+            atomicAdd(&counters[0], nSamples);
+    }
+}
+
+template <typename T>
+int launchRaw(const T *d_volume, uint32_t dx, uint32_t dy, uint32_t dz, const float *d_tf,
+              const kk_dvr_params *h_params, const kk_dvr_frame *h_frame, int target, uint8_t *d_rgba,
+              int width, int height, int y0, int y1, unsigned long long *d_counters, hipStream_t stream) {
+    KK_REQUIRE(d_volume && d_tf && h_params && h_frame && d_rgba, "null pointer");
+    KK_REQUIRE(dx > 0 && dy > 0 && dz > 0 && dx < (1u << 30) && dy < (1u << 30) && dz < (1u << 30),
+               "volume extent out of range");
+    KK_REQUIRE(target == KK_RAW_TARGET_SCENE || target == KK_RAW_TARGET_AABB, "unknown render target");
+    KK_REQUIRE(width > 0 && height > 0 && y0 >= 0 && y1 <= height && y0 <= y1, "bad image size or rows");
+    if (y0 == y1)
+        return KK_OK;
+    dim3 grid(div_up(width, 16), div_up(y1 - y0, 16));
+    if (d_counters)
+        raw_kernel<T, true><<<grid, THREADS, 0, stream>>>(d_volume, static_cast<int>(dx), static_cast<int>(dy),
+                                                          static_cast<int>(dz), d_tf, *h_params, *h_frame,
+                                                          target, d_rgba, width, height, y0, y1, d_counters);
+    else
+        raw_kernel<T, false><<<grid, THREADS, 0, stream>>>(d_volume, static_cast<int>(dx), static_cast<int>(dy),
+                                                           static_cast<int>(dz), d_tf, *h_params, *h_frame,
+                                                           target, d_rgba, width, height, y0, y1, nullptr);
+    KK_LAUNCH_CHECK();
+    return KK_OK;
+}
+
 template <typename T>
 int launch(const kk_vdb_device_data *h_vdb, const float *d_tf, const kk_dvr_params *h_params,
            const kk_dvr_frame *h_frame, uint8_t *d_rgba, int width, int height, int y0, int y1,
@@ -513,4 +706,18 @@ extern "C" int kk_dvr_render_stripes_u16(const kk_vdb_device_data *h_vdb, const 
     return kk::dvr::launch<uint16_t>(h_vdb, d_tf, h_params, h_frame, d_rgba, width, height, 0, height,
                                      stripe_first, stripe_stride, d_counters,
                                      static_cast<hipStream_t>(stream));
+}
+extern "C" int kk_raw_render_u8(const uint8_t *d_volume, uint32_t dx, uint32_t dy, uint32_t dz,
+                                const float *d_tf, const kk_dvr_params *h_params,
+                                const kk_dvr_frame *h_frame, int target, uint8_t *d_rgba, int width,
+                                int height, int y0, int y1, unsigned long long *d_counters, void *stream) {
+    return kk::dvr::launchRaw<uint8_t>(d_volume, dx, dy, dz, d_tf, h_params, h_frame, target, d_rgba, width,
+                                       height, y0, y1, d_counters, static_cast<hipStream_t>(stream));
+}
+extern "C" int kk_raw_render_u16(const uint16_t *d_volume, uint32_t dx, uint32_t dy, uint32_t dz,
+                                 const float *d_tf, const kk_dvr_params *h_params,
+                                 const kk_dvr_frame *h_frame, int target, uint8_t *d_rgba, int width,
+                                 int height, int y0, int y1, unsigned long long *d_counters, void *stream) {
+    return kk::dvr::launchRaw<uint16_t>(d_volume, dx, dy, dz, d_tf, h_params, h_frame, target, d_rgba, width,
+                                        height, y0, y1, d_counters, static_cast<hipStream_t>(stream));
 }

@@ -33,11 +33,33 @@ class RayCaster:
         self._frame = _lib.DvrFrame()
         self.vdb = None
         self.tf = None
+        self.volume = None
 
     @staticmethod
     def _fill(arr, value):
         for i, x in enumerate(np.asarray(value, np.float32).reshape(-1)):
             arr[i] = float(x)
+
+    def SetRAWVolume(self, volume):
+        """volume: dpbx_vdb.Volume (the dense uint8 / uint16 volume, [dz, dy, dx], on this device)."""
+        self.volume = volume
+
+    def RenderRAWVolume(self, fb: FrameBuffer, target: str = "Scene", rows=None, counters=None) -> None:
+        """RayCaster::RenderRAWVolume (src/ray_caster/ray_caster_raw_volume.cu:147-246): the marcher
+        without empty-space skipping; target "Scene" or "AABB" (RAWVolumeRenderTarget)."""
+        if self.volume is None or self.tf is None:
+            print(f"{self.ErrTag} volTex or tfTex are not set.", file=sys.stderr)
+            return
+        t = self.volume.tensor
+        sfx = "u8" if t.element_size() == 1 else "u16"
+        dz, dy, dx = t.shape
+        y0, y1 = rows if rows is not None else (0, fb.height)
+        with torch.cuda.device(self.device):
+            _lib.check(getattr(_lib.lib(), f"kk_raw_render_{sfx}")(
+                t.data_ptr(), dx, dy, dz, self.tf.tensor.data_ptr(), C.byref(self._params),
+                C.byref(self._frame), ("Scene", "AABB").index(target), fb.rgba.data_ptr(), fb.width,
+                fb.height, int(y0), int(y1), counters.data_ptr() if counters is not None else None,
+                _lib.current_stream_ptr()), "kk_raw_render")
 
     def SetDepthBoxVDB(self, vdb: DepthBoxVDB):
         self.vdb = vdb

@@ -114,6 +114,25 @@ int main(int argc, char **argv) {
     kk_stream_synchronize(nullptr);
     dfb.ReadBack(img);
     save(out + "/dvr_rgba.u8", img);
+    // the same view without empty-space skipping
+    auto rawVol = std::make_shared<HIP::Volume<uint8_t>>(vol, vdim[0], vdim[1], vdim[2]);
+    caster.SetRAWVolume(rawVol);
+    caster.RenderRAWVolume(dfb, dsz);
+    kk_stream_synchronize(nullptr);
+    dfb.ReadBack(img);
+    save(out + "/raw_rgba.u8", img);
+    caster.RenderRAWVolume(dfb, dsz, RayCaster::RayCaster::RAWVolumeRenderTarget::AABB);
+    kk_stream_synchronize(nullptr);
+    dfb.ReadBack(img);
+    save(out + "/raw_aabb_rgba.u8", img);
+    // and two inspection targets of the tracer
+    tracer.SetDisplayTreeHeight(5);
+    tracer.Render(fb, sz, RayTracer::RayTracer::RenderTarget::AABBs);
+    fb.ReadBack(img);
+    save(out + "/rt_aabbs.u8", img);
+    tracer.Render(fb, sz, RayTracer::RayTracer::RenderTarget::Normals);
+    fb.ReadBack(img);
+    save(out + "/rt_normals.u8", img);
     std::vector<uint64_t> sizes = {vdb->GetNodePoolsSize(), vdb->GetChildPoolsSize(),
                                    vdb->GetAtlasBrickToNodeIndicesSize()};
     save(out + "/vdb_sizes.u64", sizes);

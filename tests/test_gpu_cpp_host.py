@@ -94,5 +94,20 @@ def test_cpp_host_classes_match_checker(oracle, veach, tmp_path):
     dgot = np.fromfile(outd / "dvr_rgba.u8", np.uint8).reshape(DH, DW, 4)
     np.testing.assert_array_equal(dgot[..., 3], want[..., 3])
     assert np.abs(dgot[..., :3].astype(int) - want[..., :3].astype(int)).max() <= 1
+    # RAW-volume caster and two inspection targets through the C++ classes
+    rwant, _ = oracle.raw_render(vol, HEAD_TF.dat, w2s, cam.inverse_projective(dproj), dc.pos,
+                                 dc.rotation(), DW, DH)
+    rgot = np.fromfile(outd / "raw_rgba.u8", np.uint8).reshape(DH, DW, 4)
+    np.testing.assert_array_equal(rgot[..., 3], rwant[..., 3])
+    assert np.abs(rgot[..., :3].astype(int) - rwant[..., :3].astype(int)).max() <= 1
+    awant, _ = oracle.raw_render(vol, HEAD_TF.dat, w2s, cam.inverse_projective(dproj), dc.pos,
+                                 dc.rotation(), DW, DH, target="AABB")
+    agot = np.fromfile(outd / "raw_aabb_rgba.u8", np.uint8).reshape(DH, DW, 4)
+    assert np.abs(agot.astype(int) - awant.astype(int)).max() <= 1
+    for name, target, h in (("rt_aabbs.u8", "AABBs", 5), ("rt_normals.u8", "Normals", 5)):
+        want_t = oracle.rt_render_target(ref, arr, np.eye(4, dtype=np.float32), cam.inverse_projective(proj),
+                                         c.pos, c.rotation(), W, H, target, display_tree_height=h)
+        got_t = np.fromfile(outd / name, np.uint8).reshape(H, W, 4)
+        assert np.abs(got_t.astype(int) - want_t.astype(int)).max() <= 1, name
     sizes = np.fromfile(outd / "vdb_sizes.u64", np.uint64)
     assert sizes.tolist() == [len(v.nodes), len(v.child_pools), len(v.atlas_brick_to_node)]
