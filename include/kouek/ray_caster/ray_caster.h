@@ -3,7 +3,7 @@
 // src/ray_caster/ray_caster_dpbx_vdb.cu:439-532). Surfaces and textures become HIP::FrameBuffer /
 // HIP::TransferFunctionTable; the RAW volume is a HIP::Volume<T> (the reference binds an untyped
 // texture, so its SetRAWVolume / RenderRAWVolume take no type; here they are templates on the voxel
-// type). The Depth-Box VDB debug targets are not implemented.
+// type).
 #ifndef KOUEK_RAY_CASTER_RAY_CASTER_H
 #define KOUEK_RAY_CASTER_RAY_CASTER_H
 
@@ -25,6 +25,7 @@ class RayCaster : Noncopyable {
     const void *volDat = nullptr;
     uint32_t volDim[3] = {0, 0, 0};
     size_t volVoxelBytes = 0;
+    uint8_t displayLev = 0, displayLeafLayer = 0; // DPBXVDBRenderParameter
     static constexpr std::string_view ErrTag = "[RayCaster Error]";
 
   public:
@@ -41,6 +42,8 @@ class RayCaster : Noncopyable {
             volDim[i] = vol ? vol->GetDimension()[i] : 0;
     }
     void SetDepthBoxVDB(std::shared_ptr<DepthBoxVDB> vdb) { this->vdb = vdb; }
+    void SetDepthBoxVDBDisplayLevel(uint8_t lev) { displayLev = lev; }
+    void SetDepthBoxVDBDisplayLeafLayer(uint8_t layer) { displayLeafLayer = layer; }
     void SetMaximumAlpha(float maxAlpha) { rndrParam.max_alpha = maxAlpha; }
     void SetSamplingRate(float samplingRate) { rndrParam.sampling_rate = samplingRate; }
     void SetTransferFunctionTexture(std::shared_ptr<HIP::TransferFunctionTable> tfTex) { this->tfTex = tfTex; }
@@ -95,13 +98,11 @@ class RayCaster : Noncopyable {
             std::cerr << ErrTag << " at " << __FILE__ << ":" << __LINE__ << ". vdb or tfTex are not set.\n";
             return;
         }
-        if (rndrTarget != DPBXVDBRenderTarget::Scene) {
-            std::cerr << ErrTag << " only DPBXVDBRenderTarget::Scene is implemented.\n";
-            return;
-        }
-        auto fn = sizeof(T) == 1 ? kk_dvr_render_u8 : kk_dvr_render_u16;
-        KOUEK_HIP_CHECK(ErrTag.data(), fn(&vdb->GetDeviceData(), tfTex->Get(), &rndrParam, &rndrParamPerFrame,
-                                          rndrTo.Get(), rndrSz.x, rndrSz.y, 0, rndrSz.y, nullptr, nullptr));
+        auto fn = sizeof(T) == 1 ? kk_dvr_render_target_u8 : kk_dvr_render_target_u16;
+        KOUEK_HIP_CHECK(ErrTag.data(),
+                        fn(&vdb->GetDeviceData(), tfTex->Get(), &rndrParam, &rndrParamPerFrame,
+                           static_cast<int>(rndrTarget), displayLev, displayLeafLayer, rndrTo.Get(), rndrSz.x,
+                           rndrSz.y, 0, rndrSz.y, nullptr));
     }
 };
 

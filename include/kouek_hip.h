@@ -358,7 +358,7 @@ int kk_vdb_fill_atlas_u16(const uint16_t *d_volume, uint32_t dx, uint32_t dy, ui
                           void *stream);
 
 /* ================================================================================================
- * Path 2b: DVR marcher  --  kouek::RayCaster::RayCaster::RenderDepthBoxVDB<T>, Scene target
+ * Path 2b: DVR marcher  --  kouek::RayCaster::RayCaster::RenderDepthBoxVDB<T>
  *          (src/ray_caster/ray_caster_dpbx_vdb.cu:439-532)
  * ============================================================================================== */
 
@@ -402,6 +402,26 @@ int kk_dvr_render_stripes_u16(const kk_vdb_device_data *h_vdb, const float *d_tf
                               const kk_dvr_params *h_params, const kk_dvr_frame *h_frame,
                               uint8_t *d_rgba, int width, int height, int stripe_first,
                               int stripe_stride, unsigned long long *d_counters, void *stream);
+
+/* RenderDepthBoxVDB with any DPBXVDBRenderTarget (include/ray_caster/ray_caster.h:85; kernels
+ * src/ray_caster/ray_caster_dpbx_vdb.cu:284-437): AABBs colours the nodes of level display_lev
+ * (RayCaster::SetDepthBoxVDBDisplayLevel, 0 = leaves ... root_lev), Depths and
+ * PositionsAfterDepthSkip inspect the display_leaf_layer-th leaf along each ray
+ * (SetDepthBoxVDBDisplayLeafLayer). Scene forwards to kk_dvr_render_*; d_tf is only read for it. */
+enum {
+    KK_VDB_TARGET_SCENE = 0,
+    KK_VDB_TARGET_AABBS = 1,
+    KK_VDB_TARGET_DEPTHS = 2,
+    KK_VDB_TARGET_POSITIONS_AFTER_DEPTH_SKIP = 3
+};
+int kk_dvr_render_target_u8(const kk_vdb_device_data *h_vdb, const float *d_tf,
+                            const kk_dvr_params *h_params, const kk_dvr_frame *h_frame, int target,
+                            int display_lev, int display_leaf_layer, uint8_t *d_rgba, int width,
+                            int height, int y0, int y1, void *stream);
+int kk_dvr_render_target_u16(const kk_vdb_device_data *h_vdb, const float *d_tf,
+                             const kk_dvr_params *h_params, const kk_dvr_frame *h_frame, int target,
+                             int display_lev, int display_leaf_layer, uint8_t *d_rgba, int width,
+                             int height, int y0, int y1, void *stream);
 
 /* ================================================================================================
  * Path 2c: RAW-volume ray caster  --  kouek::RayCaster::RayCaster::RenderRAWVolume

@@ -333,6 +333,21 @@ def raw_render(volume: np.ndarray, tf: np.ndarray, w2s, inv_proj, eye_pos, eye_r
     return rgba, int(samples.value)
 
 
+def dvr_render_target(vdb: OracleVDB, w2s, inv_proj, eye_pos, eye_rot, W: int, H: int, target: str,
+                      display_lev: int = 0, display_leaf_layer: int = 0, sampling_rate=3.0, rows=None):
+    """One RenderDepthBoxVDB frame of an inspection target ("AABBs", "Depths",
+    "PositionsAfterDepthSkip") on the CPU -> rgba [H,W,4] u8."""
+    pr = _dvr_params(w2s, inv_proj, eye_pos, eye_rot, 0.9, sampling_rate, None)
+    rgba = np.zeros((H, W, 4), np.uint8)
+    y0, y1 = rows if rows is not None else (0, H)
+    t = ("Scene", "AABBs", "Depths", "PositionsAfterDepthSkip").index(target)
+    assert t > 0
+    lib().ko_dvr_render_target(C.c_void_p(vdb.handle), C.c_int(vdb.is16), C.byref(pr), C.c_int(t),
+                               C.c_int(display_lev), C.c_int(display_leaf_layer), _vp(rgba), C.c_int(W),
+                               C.c_int(H), C.c_int(y0), C.c_int(y1))
+    return rgba
+
+
 def dvr_render(vdb: OracleVDB, tf: np.ndarray, w2s, inv_proj, eye_pos, eye_rot, W: int, H: int,
                max_alpha=0.9, sampling_rate=3.0, shading=None, rows=None, rgba=None):
     """One RenderDepthBoxVDB(Scene) frame on the CPU -> (rgba [H,W,4] u8, number of samples taken)."""

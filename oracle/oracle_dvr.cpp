@@ -1,6 +1,7 @@
 // TEST INFRASTRUCTURE ONLY (see ko_math.h). CPU restatement of the Depth-Box VDB ray marcher:
 // RayCaster::RenderDepthBoxVDB<T> for the Scene target
-// (src/ray_caster/ray_caster_dpbx_vdb.cu:44-282, 465-531) with VDBStack, HDDA3D and DepthDDA2D of
+// and its inspection targets AABBs / Depths / PositionsAfterDepthSkip
+// (src/ray_caster/ray_caster_dpbx_vdb.cu:44-437, 465-531) with VDBStack, HDDA3D and DepthDDA2D of
 // include/ray_caster/dda.h, and of the un-accelerated RayCaster::RenderRAWVolume
 // (src/ray_caster/ray_caster_raw_volume.cu:27-246).
 //
@@ -380,6 +381,194 @@ template <typename T> struct Marcher {
         }
         finish();
     }
+
+    // ---- the inspection targets, ray_caster_dpbx_vdb.cu:284-437 -------------------------------------
+    // static_cast<uint8_t>(float) as the device does it: toward zero into 32 unsigned bits with
+    // saturation (negative and NaN -> 0), then the low byte.
+    static uint8_t ToU8(float v) {
+        uint32_t u = v > 0.f ? (v < 4294967040.f ? static_cast<uint32_t>(v) : 0xFFFFFFFFu) : 0u;
+        return static_cast<uint8_t>(u);
+    }
+    static vec3 toVec3(const int32_t p[3]) {
+        return {static_cast<float>(p[0]), static_cast<float>(p[1]), static_cast<float>(p[2])};
+    }
+
+    // rayCastVDB :44-137 with its callbacks as std::function-free template parameters; a callback the
+    // reference passes as nullptr is a no-op lambda here.
+    template <bool Cull, typename ScnF, typename VolF, typename PushedF, typename LeafF>
+    void rayCast(Ray &eyeRay, ScnF scn, VolF vol, PushedF pushed, LeafF inLeaf) const {
+        const VDBParameter &p = vdb.param;
+        const vec3 voxPerVol = {p.voxPerVol[0], p.voxPerVol[1], p.voxPerVol[2]};
+        HitShell hit = HitAABB(eyeRay, AABB{{0.f, 0.f, 0.f}, {1.f, 1.f, 1.f}});
+        if (Cull && hit.tEnter >= hit.tExit)
+            return;
+        scn(hit.tEnter, hit.tExit);
+        eyeRay.pos *= voxPerVol;
+        eyeRay.dir = normalize(eyeRay.dir * voxPerVol);
+        hit = HitAABB(eyeRay, AABB{{0.f, 0.f, 0.f}, voxPerVol});
+        if (Cull && hit.tEnter >= hit.tExit)
+            return;
+        vol(hit.tEnter, hit.tExit);
+        hit = HitAABB(eyeRay, AABB{{0.f, 0.f, 0.f}, {p.voxPerVDB, p.voxPerVDB, p.voxPerVDB}});
+        if (hit.tEnter >= hit.tExit)
+            return;
+
+        int lev = p.rootLev + 1;
+        float tExits[MaxLevelNum - 1] = {0.f, 0.f};
+        Node nodes[MaxLevelNum - 1] = {};
+        auto push = [&](uint32_t rel, float tExit) {
+            --lev;
+            nodes[lev - 1] = vdb.GetNode(static_cast<uint8_t>(lev), rel);
+            tExits[lev - 1] = tExit;
+        };
+        push(0, hit.tExit - Eps);
+        HDDA3D h = HDDA3D::Create(hit.tEnter + Eps, eyeRay);
+        h.Prepare({0.f, 0.f, 0.f}, p.voxsPerChild[p.rootLev]);
+        pushed(h.tCurr, lev, nodes[lev - 1]);
+
+        while (lev != p.rootLev + 1 && [&]() {
+            for (int k = 0; k < 3; ++k)
+                if (h.chPos[k] < 0 || h.chPos[k] >= p.dims[lev])
+                    return false;
+            return true;
+        }()) {
+            h.Next();
+            uint32_t ch = vdb.GetChild(static_cast<uint8_t>(lev), nodes[lev - 1].childPoolOffsRelative, h.chPos);
+            if (ch != UndefRltIdx) {
+                if (lev == 1) {
+                    h.tCurr += Eps;
+                    InLeaf param{h.tCurr, h.tNext - Eps, vdb.GetNode(0, ch)};
+                    if (!inLeaf(param))
+                        break;
+                    h.Step();
+                } else {
+                    push(ch, h.tNext - Eps);
+                    h.tCurr += Eps;
+                    h.Prepare(toVec3(nodes[lev - 1].pos), p.voxsPerChild[lev]);
+                    pushed(h.tCurr, lev, nodes[lev - 1]);
+                }
+            } else
+                h.Step();
+            while (h.tCurr >= tExits[lev - 1]) {
+                ++lev;
+                if (lev == p.rootLev + 1)
+                    break;
+                h.Prepare(toVec3(nodes[lev - 1].pos), p.voxsPerChild[lev]);
+            }
+        }
+    }
+
+    vec3 atlasBrickMin(const Node &leaf) const {
+        const VDBParameter &p = vdb.param;
+        return {static_cast<float>(leaf.brickPosInAtlas[0] * p.voxPerAtlasBrick + p.apronDepWid),
+                static_cast<float>(leaf.brickPosInAtlas[1] * p.voxPerAtlasBrick + p.apronDepWid),
+                static_cast<float>(leaf.brickPosInAtlas[2] * p.voxPerAtlasBrick + p.apronDepWid)};
+    }
+    static void store(vec3 rgb, float a, uint8_t out[4]) {
+        out[0] = ToU8(255.f * rgb.x);
+        out[1] = ToU8(255.f * rgb.y);
+        out[2] = ToU8(255.f * rgb.z);
+        out[3] = ToU8(255.f * a);
+    }
+
+    // renderAABBs :284-323: every node of level displayLev the ray enters adds its entry point,
+    // normalised to the node, at half opacity; the box tests of scene and volume do not cull.
+    void renderAABBs(int displayLev, Ray eyeRay, uint8_t out[4]) const {
+        const VDBParameter &p = vdb.param;
+        constexpr float AlphaPerLev = .5f;
+        vec3 rgb = {0.f, 0.f, 0.f};
+        float a = 0.f;
+        auto nop = [](float, float) {};
+        rayCast<false>(
+            eyeRay, nop, nop,
+            [&](float tCurr, int lev, const Node &node) {
+                if (lev == displayLev) {
+                    vec3 pos = (eyeRay.pos + tCurr * eyeRay.dir - toVec3(node.pos)) /
+                               (lev == p.rootLev ? p.voxPerVDB : p.voxsPerChild[lev + 1]);
+                    rgb = rgb + (1.f - a) * AlphaPerLev * pos;
+                    a = a + (1.f - a) * AlphaPerLev;
+                }
+            },
+            [&](InLeaf &param) {
+                if (displayLev == 0) {
+                    vec3 posInBrick = eyeRay.pos + param.tCurr * eyeRay.dir - toVec3(param.leaf.pos);
+                    rgb = rgb + (1.f - a) * AlphaPerLev * (posInBrick / p.voxsPerChild[1]);
+                    a = a + (1.f - a) * AlphaPerLev;
+                }
+                return true;
+            });
+        store(rgb, a, out);
+    }
+
+    // renderDepths :325-376: the displayLeafLayer-th leaf along the ray shows the depth value its
+    // entry face holds (grey), or red where the ray does not enter through a face.
+    void renderDepths(int displayLeafLayer, Ray eyeRay, uint8_t out[4]) const {
+        const VDBParameter &p = vdb.param;
+        vec3 rgb = {0.f, 0.f, 0.f};
+        float a = 0.f;
+        int layer = 0;
+        auto nop = [](float, float) {};
+        rayCast<true>(
+            eyeRay, nop, nop, [](float, int, const Node &) {},
+            [&](InLeaf &param) {
+                if (layer != displayLeafLayer) {
+                    layer = (layer + 1) & 0xFF; // a uint8_t counter in the reference
+                    return true;
+                }
+                vec3 posInBrick = eyeRay.pos + param.tCurr * eyeRay.dir - toVec3(param.leaf.pos);
+                vec3 abm = atlasBrickMin(param.leaf);
+                DepthDDA2D d;
+                if (d.Init(param.tCurr, p.voxsPerChild[1], p.minDepPosValInBrick, p.maxDepPosValInBrick,
+                           posInBrick, eyeRay)) {
+                    T dep = atlasPoint(abm.x + d.posInBrick[0], abm.y + d.posInBrick[1], abm.z + d.posInBrick[2]);
+                    float depNorm = dep / p.voxsPerChild[1];
+                    rgb = {depNorm, depNorm, depNorm};
+                } else
+                    rgb = {1.f, 0.f, 0.f};
+                a = 1.f;
+                return false;
+            });
+        store(rgb, a, out);
+    }
+
+    // renderPositionsAfterDepthSkip :378-437: where sampling would start in the displayLeafLayer-th
+    // leaf after the depth skip, normalised to the brick; a leaf skipped whole passes the ray on
+    // without counting as a layer.
+    void renderPositionsAfterDepthSkip(int displayLeafLayer, Ray eyeRay, uint8_t out[4]) const {
+        const VDBParameter &p = vdb.param;
+        const vec3 voxPerVol = {p.voxPerVol[0], p.voxPerVol[1], p.voxPerVol[2]};
+        vec3 rgb = {0.f, 0.f, 0.f};
+        float a = 0.f;
+        float step = 0.f;
+        uint32_t maxStepCnt = 0;
+        int layer = 0;
+        rayCast<true>(
+            eyeRay,
+            [&](float tEnter, float tExit) {
+                vec3 d = (tExit - tEnter) * eyeRay.dir;
+                maxStepCnt = static_cast<uint32_t>(std::ceil(
+                    rp.samplingRate * length(d) * gmax(voxPerVol.x, gmax(voxPerVol.y, voxPerVol.z))));
+            },
+            [&](float tEnter, float tExit) { step = (tExit - tEnter) / (maxStepCnt - 1); },
+            [](float, int, const Node &) {},
+            [&](InLeaf &param) {
+                if (layer != displayLeafLayer) {
+                    layer = (layer + 1) & 0xFF;
+                    return true;
+                }
+                param.tCurr = step * std::ceil(param.tCurr / step);
+                vec3 brickMinVoxPos = toVec3(param.leaf.pos);
+                vec3 posInBrick = eyeRay.pos + param.tCurr * eyeRay.dir - brickMinVoxPos;
+                if (depthSkip(param, posInBrick, atlasBrickMin(param.leaf), eyeRay))
+                    return true;
+                param.tCurr = step * std::ceil(param.tCurr / step);
+                posInBrick = eyeRay.pos + param.tCurr * eyeRay.dir - brickMinVoxPos;
+                rgb = posInBrick / p.voxsPerChild[1];
+                a = 1.f;
+                return false;
+            });
+        store(rgb, a, out);
+    }
 };
 
 template <typename T>
@@ -415,6 +604,50 @@ void renderDVR(const VDB<T> &vdb, const float *tf, const RenderParam &rp, uint8_
     }
     if (samplesOut)
         *samplesOut = total;
+}
+
+
+// ray_caster_dpbx_vdb.cu:475-501
+inline Ray makeEyeRay(const RenderParam &rp, int x, int y, int W, int H) {
+    Ray eyeRay;
+    vec4 tmp;
+    tmp.z = static_cast<float>(W);
+    tmp.w = static_cast<float>(H);
+    tmp.x = (2.f * x + 1.f - tmp.z) / tmp.z;
+    tmp.y = (2.f * y + 1.f - tmp.w) / tmp.w;
+    tmp.z = 1.f;
+    tmp.w = 1.f;
+    tmp = rp.invProj * tmp;
+    eyeRay.dir = {tmp.x, tmp.y, tmp.z};
+    eyeRay.dir = rp.eyeRot * normalize(eyeRay.dir);
+    tmp = {eyeRay.dir.x, eyeRay.dir.y, eyeRay.dir.z, 0.f};
+    tmp = rp.w2s * tmp;
+    eyeRay.dir = {tmp.x, tmp.y, tmp.z};
+    eyeRay.dir = normalize(eyeRay.dir);
+    tmp = {rp.eyePos.x, rp.eyePos.y, rp.eyePos.z, 1.f};
+    tmp = rp.w2s * tmp;
+    eyeRay.pos = {tmp.x, tmp.y, tmp.z};
+    return eyeRay;
+}
+
+// targets 1 = AABBs, 2 = Depths, 3 = PositionsAfterDepthSkip (DPBXVDBRenderTarget, ray_caster.h:85)
+template <typename T>
+void renderVDBTarget(const VDB<T> &vdb, const RenderParam &rp, int target, int displayLev,
+                     int displayLeafLayer, uint8_t *rgba, int W, int H, int y0, int y1) {
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int y = y0; y < y1; ++y) {
+        Marcher<T> m{vdb, nullptr, rp};
+        for (int x = 0; x < W; ++x) {
+            Ray eyeRay = makeEyeRay(rp, x, y, W, H);
+            uint8_t *out = rgba + 4 * (static_cast<size_t>(y) * W + x);
+            if (target == 1)
+                m.renderAABBs(displayLev, eyeRay, out);
+            else if (target == 2)
+                m.renderDepths(displayLeafLayer, eyeRay, out);
+            else
+                m.renderPositionsAfterDepthSkip(displayLeafLayer, eyeRay, out);
+        }
+    }
 }
 
 // ---- RayCaster::RenderRAWVolume (src/ray_caster/ray_caster_raw_volume.cu:27-246) ---------------------
@@ -592,8 +825,7 @@ struct ko_dvr_params {
     float lightPos[3], lightCol[3];
 };
 
-void ko_dvr_render(const void *vdbHandle, int is16, const float *tf256x4, const ko_dvr_params *pr,
-                   uint8_t *rgba, int W, int H, int y0, int y1, uint64_t *samplesOut) {
+static RenderParam toRenderParam(const ko_dvr_params *pr) {
     RenderParam rp;
     std::memcpy(&rp.w2s, pr->w2s, 64);
     std::memcpy(&rp.invProj, pr->invProj, 64);
@@ -608,6 +840,25 @@ void ko_dvr_render(const void *vdbHandle, int is16, const float *tf256x4, const 
     rp.shiness = pr->shiness;
     rp.lightPos = {pr->lightPos[0], pr->lightPos[1], pr->lightPos[2]};
     rp.lightCol = {pr->lightCol[0], pr->lightCol[1], pr->lightCol[2]};
+    return rp;
+}
+
+// The inspection targets of RenderDepthBoxVDB: 1 = AABBs, 2 = Depths, 3 = PositionsAfterDepthSkip.
+void ko_dvr_render_target(const void *vdbHandle, int is16, const ko_dvr_params *pr, int target,
+                          int displayLev, int displayLeafLayer, uint8_t *rgba, int W, int H, int y0,
+                          int y1) {
+    RenderParam rp = toRenderParam(pr);
+    if (is16)
+        renderVDBTarget(*static_cast<const VDB<uint16_t> *>(vdbHandle), rp, target, displayLev,
+                        displayLeafLayer, rgba, W, H, y0, y1);
+    else
+        renderVDBTarget(*static_cast<const VDB<uint8_t> *>(vdbHandle), rp, target, displayLev,
+                        displayLeafLayer, rgba, W, H, y0, y1);
+}
+
+void ko_dvr_render(const void *vdbHandle, int is16, const float *tf256x4, const ko_dvr_params *pr,
+                   uint8_t *rgba, int W, int H, int y0, int y1, uint64_t *samplesOut) {
+    RenderParam rp = toRenderParam(pr);
     if (is16)
         renderDVR(*static_cast<const VDB<uint16_t> *>(vdbHandle), tf256x4, rp, rgba, W, H, y0, y1,
                   samplesOut);

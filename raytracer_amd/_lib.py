@@ -106,6 +106,7 @@ def _declare(l):
         getattr(l, f"kk_dvr_render_{sfx}").argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]
         getattr(l, f"kk_raw_render_{sfx}").argtypes = [vp, u32, u32, u32, vp, vp, vp, i32, vp, i32, i32, i32, i32, vp, vp]
         getattr(l, f"kk_dvr_render_stripes_{sfx}").argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]
+        getattr(l, f"kk_dvr_render_target_{sfx}").argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, i32, i32, i32, i32, vp]
     l.kk_vdb_plan_build.argtypes = [u32, u32, u32, vp, C.c_uint8, i32, vp, vp]
     l.kk_vdb_wire.argtypes = [vp, vp, vp, vp, vp]
     for name in ("kk_malloc", "kk_free", "kk_memcpy_h2d", "kk_memcpy_d2h", "kk_memset",

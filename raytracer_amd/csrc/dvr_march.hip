@@ -1,5 +1,5 @@
-// Direct volume rendering of a Depth-Box VDB: RayCaster::RenderDepthBoxVDB<T>, Scene target
-// (src/ray_caster/ray_caster_dpbx_vdb.cu:44-282, 465-531; VDBStack / HDDA3D / DepthDDA2D of
+// Direct volume rendering of a Depth-Box VDB: RayCaster::RenderDepthBoxVDB<T>, Scene target and the
+// three inspection targets (src/ray_caster/ray_caster_dpbx_vdb.cu:44-437, 465-531; VDBStack / HDDA3D / DepthDDA2D of
 // include/ray_caster/dda.h), one lane per pixel, a wave covers an 8 x 8 pixel tile so that its lanes
 // walk the same bricks.
 //
@@ -622,6 +622,227 @@ __global__ __launch_bounds__(THREADS) void raw_kernel(const T *__restrict__ vol,
     }
 }
 
+// ---- inspection targets of RenderDepthBoxVDB (src/ray_caster/ray_caster_dpbx_vdb.cu:284-437) ---------
+// AABBs: every node of level displayLev the ray enters adds its entry point, normalised to the node, at
+// half opacity (the scene / volume box tests do not cull here). Depths: the depth value on the entry
+// face of the displayLeafLayer-th leaf along the ray (red where the ray does not enter through a
+// face). PositionsAfterDepthSkip: where sampling starts in that leaf after the depth skip. Colours are
+// converted with the saturating float -> u8 cast of the device.
+KK_D uint8_t satU8(float v) {
+    const uint32_t u = v > 0.f ? (v < 4294967040.f ? static_cast<uint32_t>(v) : 0xFFFFFFFFu) : 0u;
+    return static_cast<uint8_t>(u);
+}
+
+KK_D Ray makeEyeRay(const kk_dvr_params &rp, const kk_dvr_frame &fr, int x, int y, int W, int H) {
+    m4 invProj, w2s;
+    m3 rot;
+    for (int c = 0; c < 4; ++c) {
+        invProj.c[c] = {rp.inv_proj[4 * c], rp.inv_proj[4 * c + 1], rp.inv_proj[4 * c + 2],
+                        rp.inv_proj[4 * c + 3]};
+        w2s.c[c] = {rp.w2s[4 * c], rp.w2s[4 * c + 1], rp.w2s[4 * c + 2], rp.w2s[4 * c + 3]};
+    }
+    for (int c = 0; c < 3; ++c)
+        rot.c[c] = {fr.eye_rot[3 * c], fr.eye_rot[3 * c + 1], fr.eye_rot[3 * c + 2]};
+    Ray r;
+    f4 tmp;
+    tmp.z = static_cast<float>(W);
+    tmp.w = static_cast<float>(H);
+    tmp.x = (2.f * x + 1.f - tmp.z) / tmp.z;
+    tmp.y = (2.f * y + 1.f - tmp.w) / tmp.w;
+    tmp.z = 1.f;
+    tmp.w = 1.f;
+    tmp = invProj * tmp;
+    r.dir = {tmp.x, tmp.y, tmp.z};
+    r.dir = rot * normalize(r.dir);
+    tmp = {r.dir.x, r.dir.y, r.dir.z, 0.f};
+    tmp = w2s * tmp;
+    r.dir = normalize(F3(tmp.x, tmp.y, tmp.z));
+    tmp = w2s * f4{fr.eye_pos[0], fr.eye_pos[1], fr.eye_pos[2], 1.f};
+    r.pos = {tmp.x, tmp.y, tmp.z};
+    return r;
+}
+
+template <typename T>
+__global__ __launch_bounds__(THREADS) void vdb_target_kernel(const kk_vdb_device_data vdb,
+                                                             const kk_dvr_params rp,
+                                                             const kk_dvr_frame fr, int target,
+                                                             int displayLev, int displayLeafLayer,
+                                                             uint8_t *__restrict__ rgba, int W, int H,
+                                                             int y0, int y1) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int x = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
+    const int y = y0 + static_cast<int>(blockIdx.y) * 16 + (wave >> 1) * 8 + (lane >> 3);
+    if (x >= W || y >= y1)
+        return;
+    const kk_vdb_param &p = vdb.vdb_param;
+    const T *__restrict__ atlas = static_cast<const T *>(vdb.atlas);
+    const int A = p.vox_per_atlas_brick;
+    const size_t brickVox = static_cast<size_t>(A) * A * A;
+    const f3 voxPerVol = {p.vox_per_vol[0], p.vox_per_vol[1], p.vox_per_vol[2]};
+    const float dims0f = p.voxs_per_child[1];
+    const bool cull = target != KK_VDB_TARGET_AABBS;
+    constexpr float AlphaPerLev = .5f;
+
+    Ray ray = makeEyeRay(rp, fr, x, y, W, H);
+    f3 rgb = {0.f, 0.f, 0.f};
+    float a = 0.f, step = 0.f;
+    int layer = 0;
+
+    // point read of the depth shell at brick-local voxel q (0 outside the brick)
+    auto depthAt = [&](const T *brick, i3 q) -> T {
+        const int lx = q.x + p.apron_dep_wid, ly = q.y + p.apron_dep_wid, lz = q.z + p.apron_dep_wid;
+        if (lx < 0 || lx >= A || ly < 0 || ly >= A || lz < 0 || lz >= A)
+            return 0;
+        return brick[(static_cast<size_t>(lz) * A + ly) * A + lx];
+    };
+    // one node of the shown level: its entry point, normalised to the node's extent
+    auto blend = [&](f3 pos) {
+        rgb = rgb + (1.f - a) * AlphaPerLev * pos;
+        a = a + (1.f - a) * AlphaPerLev;
+    };
+
+    float tEnter, tExit;
+    HitAABB(ray, AABB{F3(0.f), F3(1.f)}, tEnter, tExit);
+    bool go = !(cull && tEnter >= tExit);
+    if (go) {
+        uint32_t maxStepCnt = 0;
+        if (target == KK_VDB_TARGET_POSITIONS_AFTER_DEPTH_SKIP)
+            maxStepCnt = static_cast<uint32_t>(
+                ceilf(rp.sampling_rate * length((tExit - tEnter) * ray.dir) *
+                      gmax(voxPerVol.x, gmax(voxPerVol.y, voxPerVol.z))));
+        ray.pos = ray.pos * voxPerVol;
+        ray.dir = normalize(ray.dir * voxPerVol);
+        HitAABB(ray, AABB{F3(0.f), voxPerVol}, tEnter, tExit);
+        go = !(cull && tEnter >= tExit);
+        if (go)
+            step = (tExit - tEnter) / (maxStepCnt - 1);
+    }
+    if (go) {
+        HitAABB(ray, AABB{F3(0.f), F3(p.vox_per_vdb)}, tEnter, tExit);
+        go = !(tEnter >= tExit);
+    }
+    if (go) {
+        int lev = p.root_lev;
+        float tExits[2] = {0.f, 0.f};
+        kk_vdb_node nodes[2];
+        nodes[0] = nodes[1] = vdb.node_pools[p.node_starts[p.root_lev]];
+        tExits[lev - 1] = tExit - Eps;
+        HDDA3D h;
+        h.sign = {sgn(ray.dir.x), sgn(ray.dir.y), sgn(ray.dir.z)};
+        h.mask = {0, 0, 0};
+        h.tCurr = tEnter + Eps;
+        h.tNext = 0.f;
+        h.Prepare(ray, F3(0.f), p.voxs_per_child[p.root_lev]);
+        if (target == KK_VDB_TARGET_AABBS && lev == displayLev)
+            blend((ray.pos + h.tCurr * ray.dir - toF3(nodes[lev - 1].pos)) / p.vox_per_vdb);
+
+        for (int guard = 0; guard < (1 << 20) && lev != p.root_lev + 1; ++guard) {
+            const int dimLev = p.dims[lev];
+            if (h.chPos.x < 0 || h.chPos.x >= dimLev || h.chPos.y < 0 || h.chPos.y >= dimLev ||
+                h.chPos.z < 0 || h.chPos.z >= dimLev)
+                break;
+            h.Next();
+            const int l2 = p.log2_dims[lev];
+            const uint32_t rel = (static_cast<uint32_t>(h.chPos.z) << (l2 << 1)) |
+                                 (static_cast<uint32_t>(h.chPos.y) << l2) | static_cast<uint32_t>(h.chPos.x);
+            const uint32_t ch =
+                vdb.child_pools[p.child_starts[lev - 1] + nodes[lev - 1].child_pool_offs_relative + rel];
+            if (ch == UndefRltIdx) {
+                h.Step();
+            } else if (lev > 1) {
+                const float pushedExit = h.tNext - Eps;
+                --lev;
+                nodes[lev - 1] = vdb.node_pools[p.node_starts[lev] + ch];
+                tExits[lev - 1] = pushedExit;
+                h.tCurr += Eps;
+                h.Prepare(ray, toF3(nodes[lev - 1].pos), p.voxs_per_child[lev]);
+                if (target == KK_VDB_TARGET_AABBS && lev == displayLev)
+                    blend((ray.pos + h.tCurr * ray.dir - toF3(nodes[lev - 1].pos)) /
+                          p.voxs_per_child[lev + 1]);
+            } else {
+                h.tCurr += Eps;
+                float tCurr = h.tCurr;
+                const float tLeafExit = h.tNext - Eps;
+                const kk_vdb_node leaf = vdb.node_pools[p.node_starts[0] + ch];
+                const f3 brickMin = toF3(leaf.pos);
+                const T *__restrict__ brick = atlas + brickVox * ch;
+                bool done = false;
+                if (target == KK_VDB_TARGET_AABBS) {
+                    if (displayLev == 0)
+                        blend((ray.pos + tCurr * ray.dir - brickMin) / dims0f);
+                } else if (layer != displayLeafLayer) {
+                    layer = (layer + 1) & 0xFF; // a uint8_t counter in the reference
+                } else if (target == KK_VDB_TARGET_DEPTHS) {
+                    const f3 pib = ray.pos + tCurr * ray.dir - brickMin;
+                    DepthDDA2D d;
+                    if (d.Init(tCurr, dims0f, p.min_dep_pos_val_in_brick, p.max_dep_pos_val_in_brick, pib, ray)) {
+                        const float depNorm = static_cast<float>(depthAt(brick, d.posInBrick)) / dims0f;
+                        rgb = {depNorm, depNorm, depNorm};
+                    } else
+                        rgb = {1.f, 0.f, 0.f};
+                    a = 1.f;
+                    done = true;
+                } else {
+                    tCurr = step * ceilf(tCurr / step);
+                    f3 pib = ray.pos + tCurr * ray.dir - brickMin;
+                    bool skipped = false;
+                    DepthDDA2D d;
+                    if (d.Init(tCurr, dims0f, p.min_dep_pos_val_in_brick, p.max_dep_pos_val_in_brick, pib, ray))
+                        while (static_cast<float>(depthAt(brick, d.posInBrick)) > d.dep) {
+                            if (d.t >= tLeafExit) {
+                                skipped = true;
+                                break;
+                            }
+                            tCurr = d.t;
+                            d.StepNext();
+                        }
+                    if (!skipped) {
+                        tCurr = step * ceilf(tCurr / step);
+                        pib = ray.pos + tCurr * ray.dir - brickMin;
+                        rgb = pib / dims0f;
+                        a = 1.f;
+                        done = true;
+                    }
+                }
+                if (done)
+                    break;
+                h.Step();
+            }
+            while (h.tCurr >= tExits[lev - 1]) {
+                ++lev;
+                if (lev == p.root_lev + 1)
+                    break;
+                h.Prepare(ray, toF3(nodes[lev - 1].pos), p.voxs_per_child[lev]);
+            }
+        }
+    }
+    reinterpret_cast<uchar4 *>(rgba)[static_cast<size_t>(y) * W + x] =
+        make_uchar4(satU8(255.f * rgb.x), satU8(255.f * rgb.y), satU8(255.f * rgb.z), satU8(255.f * a));
+}
+
+template <typename T>
+int launchTarget(const kk_vdb_device_data *h_vdb, const kk_dvr_params *h_params, const kk_dvr_frame *h_frame,
+                 int target, int displayLev, int displayLeafLayer, uint8_t *d_rgba, int width, int height,
+                 int y0, int y1, hipStream_t stream) {
+    KK_REQUIRE(h_vdb && h_params && h_frame && d_rgba, "null pointer");
+    KK_REQUIRE(h_vdb->node_pools && h_vdb->child_pools && h_vdb->atlas, "VDB arrays missing");
+    KK_REQUIRE(h_vdb->voxel_bytes == sizeof(T), "voxel type does not match the VDB");
+    KK_REQUIRE(h_vdb->vdb_param.root_lev >= 1 && h_vdb->vdb_param.root_lev <= 2, "root level out of range");
+    KK_REQUIRE(target == KK_VDB_TARGET_AABBS || target == KK_VDB_TARGET_DEPTHS ||
+                   target == KK_VDB_TARGET_POSITIONS_AFTER_DEPTH_SKIP,
+               "unknown render target");
+    KK_REQUIRE(displayLev >= 0 && displayLev <= 255 && displayLeafLayer >= 0 && displayLeafLayer <= 255,
+               "display level / leaf layer out of range");
+    KK_REQUIRE(width > 0 && height > 0 && y0 >= 0 && y1 <= height && y0 <= y1, "bad image size or rows");
+    if (y0 == y1)
+        return KK_OK;
+    dim3 grid(div_up(width, 16), div_up(y1 - y0, 16));
+    vdb_target_kernel<T><<<grid, THREADS, 0, stream>>>(*h_vdb, *h_params, *h_frame, target, displayLev,
+                                                       displayLeafLayer, d_rgba, width, height, y0, y1);
+    KK_LAUNCH_CHECK();
+    return KK_OK;
+}
+
 template <typename T>
 int launchRaw(const T *d_volume, uint32_t dx, uint32_t dy, uint32_t dz, const float *d_tf,
               const kk_dvr_params *h_params, const kk_dvr_frame *h_frame, int target, uint8_t *d_rgba,
@@ -720,4 +941,24 @@ extern "C" int kk_raw_render_u16(const uint16_t *d_volume, uint32_t dx, uint32_t
                                  int height, int y0, int y1, unsigned long long *d_counters, void *stream) {
     return kk::dvr::launchRaw<uint16_t>(d_volume, dx, dy, dz, d_tf, h_params, h_frame, target, d_rgba, width,
                                         height, y0, y1, d_counters, static_cast<hipStream_t>(stream));
+}
+extern "C" int kk_dvr_render_target_u8(const kk_vdb_device_data *h_vdb, const float *d_tf,
+                                       const kk_dvr_params *h_params, const kk_dvr_frame *h_frame,
+                                       int target, int display_lev, int display_leaf_layer,
+                                       uint8_t *d_rgba, int width, int height, int y0, int y1, void *stream) {
+    if (target == KK_VDB_TARGET_SCENE)
+        return kk::dvr::launch<uint8_t>(h_vdb, d_tf, h_params, h_frame, d_rgba, width, height, y0, y1, 0, 1,
+                                        nullptr, static_cast<hipStream_t>(stream));
+    return kk::dvr::launchTarget<uint8_t>(h_vdb, h_params, h_frame, target, display_lev, display_leaf_layer,
+                                          d_rgba, width, height, y0, y1, static_cast<hipStream_t>(stream));
+}
+extern "C" int kk_dvr_render_target_u16(const kk_vdb_device_data *h_vdb, const float *d_tf,
+                                        const kk_dvr_params *h_params, const kk_dvr_frame *h_frame,
+                                        int target, int display_lev, int display_leaf_layer,
+                                        uint8_t *d_rgba, int width, int height, int y0, int y1, void *stream) {
+    if (target == KK_VDB_TARGET_SCENE)
+        return kk::dvr::launch<uint16_t>(h_vdb, d_tf, h_params, h_frame, d_rgba, width, height, y0, y1, 0,
+                                         1, nullptr, static_cast<hipStream_t>(stream));
+    return kk::dvr::launchTarget<uint16_t>(h_vdb, h_params, h_frame, target, display_lev, display_leaf_layer,
+                                           d_rgba, width, height, y0, y1, static_cast<hipStream_t>(stream));
 }

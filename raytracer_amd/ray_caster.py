@@ -34,6 +34,8 @@ class RayCaster:
         self.vdb = None
         self.tf = None
         self.volume = None
+        self._display_lev = 0
+        self._display_leaf_layer = 0
 
     @staticmethod
     def _fill(arr, value):
@@ -64,6 +66,14 @@ class RayCaster:
     def SetDepthBoxVDB(self, vdb: DepthBoxVDB):
         self.vdb = vdb
 
+    def SetDepthBoxVDBDisplayLevel(self, lev: int):
+        """Level whose nodes the AABBs target colours: 0 = leaf bricks ... rootLev."""
+        self._display_lev = int(lev) & 0xFF
+
+    def SetDepthBoxVDBDisplayLeafLayer(self, layer: int):
+        """Which leaf along each ray (0 = first) the Depths / PositionsAfterDepthSkip targets show."""
+        self._display_leaf_layer = int(layer) & 0xFF
+
     def SetTransferFunctionTexture(self, tf: TransferFunctionTable):
         self.tf = tf
 
@@ -93,13 +103,26 @@ class RayCaster:
     def UnsetShading(self):
         self._params.use_shading = 0
 
-    def RenderDepthBoxVDB(self, fb: FrameBuffer, rows=None, counters=None, stripes=None) -> None:
-        """One frame (Scene target) into fb. `rows` = (y0, y1) renders those rows only; `stripes` =
-        (first, stride) renders the 16-row stripes first, first + stride, ... (one GPU's share)."""
+    DPBXVDB_RENDER_TARGETS = ("Scene", "AABBs", "Depths", "PositionsAfterDepthSkip")
+
+    def RenderDepthBoxVDB(self, fb: FrameBuffer, rows=None, counters=None, stripes=None,
+                          target: str = "Scene") -> None:
+        """One frame into fb. `rows` = (y0, y1) renders those rows only; `stripes` = (first, stride)
+        renders the 16-row stripes first, first + stride, ... (one GPU's share; Scene only). `target` is
+        a DPBXVDBRenderTarget (include/ray_caster/ray_caster.h:85)."""
         if self.vdb is None or self.tf is None or not self.vdb.IsComplete():
             print(f"{self.ErrTag} vdb or tfTex are not set.", file=sys.stderr)
             return
         sfx = "u8" if self.vdb.voxel_bytes == 1 else "u16"
+        if target != "Scene":
+            y0, y1 = rows if rows is not None else (0, fb.height)
+            with torch.cuda.device(self.device):
+                _lib.check(getattr(_lib.lib(), f"kk_dvr_render_target_{sfx}")(
+                    C.byref(self.vdb.GetDeviceData()), self.tf.tensor.data_ptr(), C.byref(self._params),
+                    C.byref(self._frame), self.DPBXVDB_RENDER_TARGETS.index(target), self._display_lev,
+                    self._display_leaf_layer, fb.rgba.data_ptr(), fb.width, fb.height, int(y0), int(y1),
+                    _lib.current_stream_ptr()), "kk_dvr_render_target")
+            return
         if stripes is not None:
             fn, a, b = getattr(_lib.lib(), f"kk_dvr_render_stripes_{sfx}"), stripes[0], stripes[1]
         else:

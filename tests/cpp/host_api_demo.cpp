@@ -125,6 +125,17 @@ int main(int argc, char **argv) {
     kk_stream_synchronize(nullptr);
     dfb.ReadBack(img);
     save(out + "/raw_aabb_rgba.u8", img);
+    // the inspection targets of the VDB marcher
+    caster.SetDepthBoxVDBDisplayLevel(0);
+    caster.RenderDepthBoxVDB<uint8_t>(dfb, dsz, RayCaster::RayCaster::DPBXVDBRenderTarget::AABBs);
+    kk_stream_synchronize(nullptr);
+    dfb.ReadBack(img);
+    save(out + "/vdb_aabbs.u8", img);
+    caster.SetDepthBoxVDBDisplayLeafLayer(1);
+    caster.RenderDepthBoxVDB<uint8_t>(dfb, dsz, RayCaster::RayCaster::DPBXVDBRenderTarget::PositionsAfterDepthSkip);
+    kk_stream_synchronize(nullptr);
+    dfb.ReadBack(img);
+    save(out + "/vdb_positions.u8", img);
     // and two inspection targets of the tracer
     tracer.SetDisplayTreeHeight(5);
     tracer.Render(fb, sz, RayTracer::RayTracer::RenderTarget::AABBs);

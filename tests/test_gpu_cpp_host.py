@@ -104,6 +104,13 @@ def test_cpp_host_classes_match_checker(oracle, veach, tmp_path):
                                  dc.rotation(), DW, DH, target="AABB")
     agot = np.fromfile(outd / "raw_aabb_rgba.u8", np.uint8).reshape(DH, DW, 4)
     assert np.abs(agot.astype(int) - awant.astype(int)).max() <= 1
+    for name, target, lev, layer in (("vdb_aabbs.u8", "AABBs", 0, 0),
+                                     ("vdb_positions.u8", "PositionsAfterDepthSkip", 0, 1)):
+        want_t = oracle.dvr_render_target(v, w2s, cam.inverse_projective(dproj), dc.pos, dc.rotation(), DW,
+                                          DH, target, display_lev=lev, display_leaf_layer=layer)
+        got_t = np.fromfile(outd / name, np.uint8).reshape(DH, DW, 4)
+        assert np.abs(got_t.astype(int) - want_t.astype(int)).max() <= 1, name
+        assert (want_t[..., 3] > 0).mean() > 0.05
     for name, target, h in (("rt_aabbs.u8", "AABBs", 5), ("rt_normals.u8", "Normals", 5)):
         want_t = oracle.rt_render_target(ref, arr, np.eye(4, dtype=np.float32), cam.inverse_projective(proj),
                                          c.pos, c.rotation(), W, H, target, display_tree_height=h)

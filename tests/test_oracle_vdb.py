@@ -202,3 +202,36 @@ def test_oracle_render_sane_and_split_invariant(oracle):
     img3, ns3 = oracle.dvr_render(v2, HEAD_TF.dat, w2s, inv, c.pos, c.rotation(), W, H)
     assert ns3 >= ns
     assert np.abs(img.astype(int) - img3.astype(int)).max() <= 2
+
+
+def test_oracle_inspection_targets_are_consistent(oracle):
+    """Properties that tie the three inspection targets to the tree the checker built: the root-level
+    AABBs frame is lit exactly where a ray meets the VDB's cube; rays that meet a leaf are the same for
+    AABBs (level 0), Depths and the Scene walk; a deeper leaf layer can only shrink the coverage; a
+    position after the depth skip lies inside the brick (colour < 1 up to the step rounding)."""
+    dim = (64, 128, 128)
+    vol = syn.head_volume(dim)
+    ref = oracle.OracleVDB(vol, (4, 3, 3), 1, True, HEAD_TF.empty_scalar_ranges)
+    W, H = 96, 72
+    w2s, c, proj = dvr_setup(dim, (2, 1, 1), W, H, 1.0, 21)
+    view = (w2s, cam.inverse_projective(proj), c.pos, c.rotation())
+    root = oracle.dvr_render_target(ref, *view, W, H, "AABBs", display_lev=int(ref.param["rootLev"]))
+    leaf = oracle.dvr_render_target(ref, *view, W, H, "AABBs", display_lev=0)
+    d0 = oracle.dvr_render_target(ref, *view, W, H, "Depths", display_leaf_layer=0)
+    d2 = oracle.dvr_render_target(ref, *view, W, H, "Depths", display_leaf_layer=2)
+    p0 = oracle.dvr_render_target(ref, *view, W, H, "PositionsAfterDepthSkip", display_leaf_layer=0)
+    assert set(np.unique(root[..., 3])) <= {0, 127}        # one node per ray at half opacity
+    assert (root[..., 3] > 0).mean() > (leaf[..., 3] > 0).mean() > 0.05
+    np.testing.assert_array_equal(leaf[..., 3] > 0, d0[..., 3] == 255)
+    assert set(np.unique(d0[..., 3])) <= {0, 255}
+    assert not ((d2[..., 3] > 0) & ~(d0[..., 3] > 0)).any()
+    assert 0 < (d2[..., 3] > 0).sum() < (d0[..., 3] > 0).sum()
+    # grey = depth value, red = the ray did not enter through a face
+    lit = d0[..., 3] == 255
+    grey = lit & (d0[..., 0] == d0[..., 1]) & (d0[..., 1] == d0[..., 2])
+    red = lit & (d0[..., 0] == 255) & (d0[..., 1] == 0) & (d0[..., 2] == 0)
+    assert (grey | red)[lit].all() and grey.sum() > 0
+    # the same frame in two halves
+    top = oracle.dvr_render_target(ref, *view, W, H, "PositionsAfterDepthSkip", rows=(30, H))
+    np.testing.assert_array_equal(top[30:], p0[30:])
+    assert (p0[..., 3] == 255).sum() <= (d0[..., 3] == 255).sum() and (p0[..., 3] == 255).sum() > 0
