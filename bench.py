@@ -181,7 +181,7 @@ def main():
     # ---- roofline of the dominant kernel (closest_hit_accel_kernel) ---------------------------------
     # algorithmic bytes per launch: 64 B per node record visited + 48 B per triangle record tested +
     # 4 B order index + 24 B ray in + 16 B hit out, counted by the kernel's own work counters
-    alg_bytes = 64 * counters["node_fetches"] + 48 * counters["tri_tests"] + (4 + 24 + 16) * R
+    alg_bytes = 128 * counters["node_fetches"] + 48 * counters["tri_tests"] + (4 + 24 + 16) * R
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,

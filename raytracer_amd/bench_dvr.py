@@ -34,12 +34,20 @@ def run(dev: str, world: int, rank: int, dist=None, frames: int = 120, warmup: i
     if rank == 0:
         vol_t = (torch.from_numpy(syn.head_volume(dim)).to(dev) if head
                  else syn.kingsnake_volume_torch(dim, dev))
-        t0 = time.perf_counter()
-        vdb.BuildFrom(Volume(vol_t, dev), tf.empty_scalar_ranges, apron_wid=1, log2_dims=(5, 4, 3),
-                      use_depth_box=True)
-        torch.cuda.synchronize()
-        assert vdb.IsComplete(), "VDB build failed"
+        volume = Volume(vol_t, dev)
+        cold_ms = None
+        for attempt in range(2):  # the first build pays code-object loading and the allocator's growth
+            vdb = DepthBoxVDB(dev)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            vdb.BuildFrom(volume, tf.empty_scalar_ranges, apron_wid=1, log2_dims=(5, 4, 3),
+                          use_depth_box=True)
+            torch.cuda.synchronize()
+            assert vdb.IsComplete(), "VDB build failed"
+            if attempt == 0:
+                cold_ms = (time.perf_counter() - t0) * 1e3
         build = {"total_ms": round((time.perf_counter() - t0) * 1e3, 2),
+                 "first_build_ms": round(cold_ms, 2),
                  "classify_ms": round(vdb.timings["classify_ms"], 3),
                  "fill_atlas_ms": round(vdb.timings["fill_atlas_ms"], 3),
                  "leaf_bricks": int(vdb.plan.leaf_num),

@@ -12,18 +12,24 @@
 // position k, see traverse.h). How candidates are FOUND is free, as long as none is missed.
 //
 // So the binary tree is repacked once after the build, for finding candidates fast:
-//   * Node4 (128 B, one cache line) per binary node n: the boxes and ids of n's four grandchildren
-//     (a child that is a leaf takes one slot itself). Boxes are stored per axis (4 mins, 4 maxs) so a
-//     lane fetches "near" and "far" planes directly by the sign of its ray direction. Leaf slots hold
-//     the box of the leaf's triangles grown by a small pad.
-//   * TriRec (48 B) per sorted triangle position k: three vertices, face index, index of the leaf's
-//     parent node.
+//   * Wide8 (128 B = one L2 line) per wide node: up to eight descendants of a binary node, chosen by
+//     opening the child with the largest box until eight slots are filled. A slot is a binary subtree
+//     (its wide node sits at childBase + its rank among the internal slots: children are contiguous)
+//     or a leaf (a run of triangles). The slot boxes are 8-bit offsets from the record's origin in
+//     units of 2^exp per axis, rounded outwards; leaf boxes are grown by a small pad first. Slots are
+//     laid out by octant around the node's centre, so that "slot XOR ray octant" ascending is a
+//     front-to-back order and no sorting is needed.
+//   * TriRec (48 B) per triangle, stored in the order of the wide nodes (all leaf triangles of a wide
+//     node are contiguous): three vertices, face index, the leaf's parent binary node, and the sorted
+//     position k that resolves equal distances.
+// Wide nodes are made level by level from the root: one launch per level, a thread per wide node,
+// children and triangles allocated with one atomic per wave.
 // The walk uses a reciprocal-multiply slab test made conservative by a relative margin (it may visit
-// more than the reference, never less). A triangle whose Moeller-Trumbore test (same arithmetic as
-// 3rd/glm/gtx/intersect.inl:28-94) beats the best hit is accepted only after the slab test of its
-// leaf's parent box: decided by the fast test when that is outside its error margin, by the
-// reference's division form otherwise. For a ray with a (near-)zero direction component plane
-// distances become inf / NaN and the containment argument does not hold: such a ray walks with
+// more than the reference, never less). A triangle hit is taken at once; when the ray retires its
+// final hit is checked against the slab test of its leaf's parent box: decided by the fast test when
+// that is outside its error margin, by the reference's division form otherwise (a failed check walks
+// the ray again, checking every hit as it is taken). For a ray with a (near-)zero direction component
+// plane distances become inf / NaN and the containment argument does not hold: such a ray walks with
 // +-1e18 in place of the infinite reciprocal (still a superset of the reference's visits) and accepts
 // a hit only after the reference's slab test of EVERY node from the leaf's parent up to the root.
 // Rays are traced in Morton order of their origins (radix sort of (key, index)); outputs are written
@@ -31,6 +37,8 @@
 #include "kk_host.h"
 #include "kk_math.h"
 #include "traverse.h"
+
+#include <stdlib.h>
 
 namespace kk {
 namespace rsort {
@@ -49,18 +57,21 @@ constexpr int THREADS = 256;
 constexpr float LEAF_PAD = 1e-5f; // leaf boxes grow by this fraction of the scene's largest coordinate
 constexpr uint32_t EMPTY = 0xFFFFFFFFu;
 
-// 64 bytes: the four slot boxes are 8-bit offsets from `origin` in units of 2^exp per axis, rounded
-// outwards by one extra unit, so a dequantised box always contains the float box it stands for.
-struct alignas(64) Node4 {
+struct alignas(128) Wide8 {
     float origin[3];
     int8_t exp[3];
-    uint8_t pad;
-    uint8_t q[6][4];   // minx[4] maxx[4] miny[4] maxy[4] minz[4] maxz[4]
-    uint32_t child[4]; // binary node index | LEAF + first sorted position | EMPTY
-    uint16_t cnt[4];   // triangles of a leaf slot (CNT_LONG: read the count from the first TriRec)
+    uint8_t imask;      // slots that hold a binary subtree
+    uint32_t childBase; // wide node of the first such slot; the others follow in slot order
+    uint32_t triBase;   // first TriRec of this node's leaf slots
+    uint32_t leafMask;  // bits 0-7: slots that hold a leaf; LONG_RUN: off / cnt do not fit a byte
+    uint32_t triTotal;  // triangles of all leaf slots
+    uint8_t q[6][8];    // minx[8] maxx[8] miny[8] maxy[8] minz[8] maxz[8]
+    uint8_t off[8];     // first triangle of a leaf slot, relative to triBase
+    uint8_t cnt[8];     // its triangle count
+    uint32_t spare[8];
 };
-static_assert(sizeof(Node4) == 64, "half a cache line");
-constexpr uint32_t CNT_LONG = 0xFFFFu;
+static_assert(sizeof(Wide8) == 128, "one cache line");
+constexpr uint32_t LONG_RUN = 0x100u;
 
 struct alignas(16) TriRec {
     float v0[3];
@@ -68,7 +79,7 @@ struct alignas(16) TriRec {
     float v1[3];
     uint32_t parent; // binary node whose child is this triangle's leaf
     float v2[3];
-    uint32_t run; // in the first record of a leaf's run: the number of triangles in the run
+    uint32_t k; // position in the build's sorted face order
 };
 static_assert(sizeof(TriRec) == 48, "three 16-byte loads");
 
@@ -76,168 +87,301 @@ struct alignas(256) Header {
     float rootBox[6];
     uint32_t faceNum, nodeNum;
     const kk_lbvh_node *nodes; // the build's own nodes (parent boxes for the acceptance test)
+    uint32_t wideNum;
+};
+
+// A binary path fixes one more Morton bit per level, a wide level descends at least one binary level.
+constexpr int MAX_LEVELS = 32;
+struct alignas(256) BuildCtl {
+    uint32_t wideCount, triCount;
+    uint32_t bounds[MAX_LEVELS + 2]; // wide nodes of level l are [bounds[l], bounds[l + 1])
 };
 
 struct Layout {
-    size_t header, nodes, tris, parents, total;
+    size_t header, ctl, nodes, tris, parents, rootOf, total;
 };
 inline Layout layout(uint32_t faceNum, uint32_t compactedNum) {
     Layout l;
     Carver c;
     const uint32_t nodeNum = compactedNum > 1 ? compactedNum - 1 : 1;
     l.header = c.take(sizeof(Header));
-    l.nodes = c.take(sizeof(Node4) * static_cast<size_t>(nodeNum));
+    l.ctl = c.take(sizeof(BuildCtl));
+    l.nodes = c.take(sizeof(Wide8) * static_cast<size_t>(nodeNum)); // a wide node has >= 2 slots
     l.tris = c.take(sizeof(TriRec) * static_cast<size_t>(faceNum));
     l.parents = c.take(sizeof(uint32_t) * static_cast<size_t>(nodeNum)); // parent of each binary node
+    l.rootOf = c.take(sizeof(uint32_t) * static_cast<size_t>(nodeNum));  // binary root of each wide node
     l.total = c.off;
     return l;
 }
 
-__global__ __launch_bounds__(THREADS) void pack_tris_kernel(
-    const kk_lbvh_device_data *__restrict__ lbvh, const float *__restrict__ positions,
-    const uint32_t *__restrict__ tri, TriRec *__restrict__ recs, uint32_t faceNum) {
-    const uint32_t k = blockIdx.x * THREADS + threadIdx.x;
-    if (k >= faceNum)
-        return;
-    const uint32_t fi = lbvh->faces[k];
-    const uint32_t i0 = tri[3ull * fi], i1 = tri[3ull * fi + 1], i2 = tri[3ull * fi + 2];
-    const f3 a = trav::load_pos(positions, i0), b = trav::load_pos(positions, i1),
-             c = trav::load_pos(positions, i2);
-    // .parent is written by make_node4_kernel
-    float *o = reinterpret_cast<float *>(recs + k);
-    o[0] = a.x, o[1] = a.y, o[2] = a.z;
-    reinterpret_cast<uint32_t *>(o)[3] = fi;
-    o[4] = b.x, o[5] = b.y, o[6] = b.z;
-    o[8] = c.x, o[9] = c.y, o[10] = c.z;
-    reinterpret_cast<uint32_t *>(o)[11] = 0u;
-}
-
-struct Slot {
-    AABB box;
-    uint32_t child, cnt;
-};
-
-__device__ __forceinline__ Slot empty_slot() {
-    Slot s;
-    s.box.minPos = F3(__builtin_inff());
-    s.box.maxPos = F3(-__builtin_inff());
-    s.child = EMPTY;
-    s.cnt = 0u;
-    return s;
-}
-
-__device__ __forceinline__ Slot leaf_slot(const kk_lbvh_device_data *__restrict__ lbvh,
-                                          TriRec *__restrict__ recs, uint32_t leaf, uint32_t parent,
-                                          float pad) {
-    const uint32_t l = leaf & LEAF_MASK;
-    const uint32_t k0 = lbvh->compacted_faces[l];
-    const uint32_t k1 = (l == lbvh->compacted_face_num - 1) ? lbvh->face_num
-                                                            : lbvh->compacted_faces[l + 1];
-    Slot s;
-    s.box = AABB::Initial();
-    for (uint32_t k = k0; k < k1; ++k) {
-        TriRec &r = recs[k];
-        s.box.Expand(F3(r.v0[0], r.v0[1], r.v0[2]));
-        s.box.Expand(F3(r.v1[0], r.v1[1], r.v1[2]));
-        s.box.Expand(F3(r.v2[0], r.v2[1], r.v2[2]));
-        r.parent = parent; // every writer of this word writes the same value
+__global__ void init_build_kernel(const kk_lbvh_device_data *__restrict__ lbvh, Header *__restrict__ hdr,
+                                  BuildCtl *__restrict__ ctl, uint32_t *__restrict__ rootOf,
+                                  uint32_t nodeNum) {
+    const kk_lbvh_node *nodes = lbvh->internal_nodes;
+    const trav::NodeData root = trav::load_node(nodes, 0);
+    for (int a = 0; a < 3; ++a) {
+        hdr->rootBox[a] = root.box.minPos[a];
+        hdr->rootBox[3 + a] = root.box.maxPos[a];
     }
-    recs[k0].run = k1 - k0;
-    s.box.minPos = s.box.minPos - pad;
-    s.box.maxPos = s.box.maxPos + pad;
-    s.child = LEAF | k0;
-    s.cnt = k1 - k0;
-    return s;
+    hdr->faceNum = lbvh->face_num;
+    hdr->nodeNum = nodeNum;
+    hdr->nodes = nodes;
+    hdr->wideNum = 1;
+    ctl->wideCount = 1;
+    ctl->triCount = 0;
+    for (int l = 0; l < MAX_LEVELS + 2; ++l)
+        ctl->bounds[l] = l == 0 ? 0u : 1u;
+    rootOf[0] = 0;
 }
 
-__global__ __launch_bounds__(THREADS) void make_node4_kernel(
-    const kk_lbvh_device_data *__restrict__ lbvh, TriRec *__restrict__ recs,
-    Node4 *__restrict__ out, uint32_t *__restrict__ parents, Header *__restrict__ hdr,
-    uint32_t nodeNum) {
+__global__ __launch_bounds__(THREADS) void parents_kernel(const kk_lbvh_device_data *__restrict__ lbvh,
+                                                          uint32_t *__restrict__ parents,
+                                                          uint32_t nodeNum) {
     const uint32_t n = blockIdx.x * THREADS + threadIdx.x;
     if (n >= nodeNum)
         return;
-    const kk_lbvh_node *nodes = lbvh->internal_nodes;
-    const trav::NodeData root = trav::load_node(nodes, 0);
-    float scale = 0.f;
-    for (int a = 0; a < 3; ++a) {
-        scale = fmaxf(scale, fabsf(root.box.minPos[a]));
-        scale = fmaxf(scale, fabsf(root.box.maxPos[a]));
-        scale = fmaxf(scale, root.box.maxPos[a] - root.box.minPos[a]);
-    }
-    const float pad = LEAF_PAD * scale;
-    if (n == 0) {
-        for (int a = 0; a < 3; ++a) {
-            hdr->rootBox[a] = root.box.minPos[a];
-            hdr->rootBox[3 + a] = root.box.maxPos[a];
-        }
-        hdr->faceNum = lbvh->face_num;
-        hdr->nodeNum = nodeNum;
-        hdr->nodes = nodes;
-    }
-    const trav::NodeData me = trav::load_node(nodes, n);
-    const uint32_t ch[2] = {me.lft, me.rht};
+    const uint2 ch = *reinterpret_cast<const uint2 *>(lbvh->internal_nodes + n);
     if (n == 0)
         parents[0] = EMPTY;
-    if (!(ch[0] & LEAF))
-        parents[ch[0]] = n;
-    if (!(ch[1] & LEAF))
-        parents[ch[1]] = n;
-    Slot slot[4];
-    for (int s = 0; s < 2; ++s) {
-        const uint32_t c = ch[s];
-        if (s == 1 && ch[0] == ch[1] && (c & LEAF)) { // single-leaf tree: the leaf appears once
-            slot[2] = slot[3] = empty_slot();
-        } else if (c & LEAF) {
-            slot[2 * s] = leaf_slot(lbvh, recs, c, n, pad);
-            slot[2 * s + 1] = empty_slot();
-        } else {
-            const trav::NodeData g = trav::load_node(nodes, c);
-            const uint32_t gc[2] = {g.lft, g.rht};
-            for (int t = 0; t < 2; ++t) {
-                if (gc[t] & LEAF)
-                    slot[2 * s + t] = leaf_slot(lbvh, recs, gc[t], c, pad);
-                else {
-                    slot[2 * s + t].box = trav::load_node(nodes, gc[t]).box;
-                    slot[2 * s + t].child = gc[t];
-                    slot[2 * s + t].cnt = 0u;
+    if (!(ch.x & LEAF))
+        parents[ch.x] = n;
+    if (!(ch.y & LEAF))
+        parents[ch.y] = n;
+}
+
+constexpr int BT = 128; // threads of a collapse workgroup: 16 KB of slot storage in LDS
+
+// Runs between two levels: the wide nodes reserved so far end the level that is built next.
+__global__ void close_level_kernel(BuildCtl *ctl, Header *hdr, int level) {
+    const uint32_t total = ctl->wideCount;
+    ctl->bounds[level + 2] = total;
+    hdr->wideNum = total;
+}
+
+// One level of wide nodes: thread w opens the binary subtree rootOf[w] into at most eight slots,
+// reserves its children's wide nodes and its triangles' records, and writes all three. Slot boxes
+// are quantised as they are met, against the subtree's own box (grown by the leaf pad), which
+// contains them all.
+__global__ __launch_bounds__(BT) void collapse_level_kernel(
+    const kk_lbvh_device_data *__restrict__ lbvh, const float *__restrict__ positions,
+    const uint32_t *__restrict__ tri, Wide8 *__restrict__ out, TriRec *__restrict__ recs,
+    uint32_t *__restrict__ rootOf, BuildCtl *ctl, int level) {
+    __shared__ uint2 s_q[8][BT];      // x: minx miny minz maxx (bytes), y: maxy maxz
+    __shared__ uint32_t s_ref[8][BT]; // binary node, or LEAF | leaf index
+    __shared__ uint32_t s_aux[8][BT]; // leaf: its parent binary node; subtree: half box area (float)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const uint32_t start = ctl->bounds[level], end = ctl->bounds[level + 1];
+    if (start >= end)
+        return;
+    const kk_lbvh_node *__restrict__ nodes = lbvh->internal_nodes;
+    const uint32_t *__restrict__ faces = lbvh->faces;
+    const uint32_t *__restrict__ compacted = lbvh->compacted_faces;
+    const uint32_t faceNum = lbvh->face_num, leafNum = lbvh->compacted_face_num;
+
+    float pad;
+    {
+        const trav::NodeData root = trav::load_node(nodes, 0);
+        float scale = 0.f;
+        for (int a = 0; a < 3; ++a) {
+            scale = fmaxf(scale, fabsf(root.box.minPos[a]));
+            scale = fmaxf(scale, fabsf(root.box.maxPos[a]));
+            scale = fmaxf(scale, root.box.maxPos[a] - root.box.minPos[a]);
+        }
+        pad = LEAF_PAD * scale;
+    }
+    auto runOf = [&](uint32_t leaf, uint32_t &k0, uint32_t &k1) {
+        const uint32_t l = leaf & LEAF_MASK;
+        k0 = compacted[l];
+        k1 = (l == leafNum - 1) ? faceNum : compacted[l + 1];
+    };
+
+    for (uint32_t base = start + blockIdx.x * BT; base < end; base += gridDim.x * BT) {
+        const uint32_t w = base + tid;
+        const bool valid = w < end;
+        int cN = 0;
+        uint32_t childOf = 0xFFFFFFFFu; // 4 bits per slot: which opened child sits there (0xF: none)
+        uint32_t imask = 0, leafMask = 0, ci = 0, ct = 0;
+        f3 org = F3(0.f), inv = F3(0.f), extQ = F3(0.f);
+        int ex[3] = {0, 0, 0};
+        if (valid) {
+            const uint32_t n = rootOf[w];
+            const trav::NodeData me = trav::load_node(nodes, n);
+            for (int a = 0; a < 3; ++a) {
+                org[a] = me.box.minPos[a] - pad;
+                const float r = (me.box.maxPos[a] + pad - org[a]) / 253.f;
+                int e = r > 0.f ? ilogbf(r) + 1 : -100; // 2^e > extent / 253: offsets stay below 254
+                e = e < -100 ? -100 : (e > 100 ? 100 : e);
+                ex[a] = e;
+                inv[a] = ldexpf(1.f, -e);
+                extQ[a] = (me.box.maxPos[a] + pad - org[a]) * inv[a]; // the node's extent in byte units
+            }
+            // quantised outwards by one extra unit: the byte box contains the float box
+            auto put = [&](int j, uint32_t c, uint32_t parent) {
+                AABB b;
+                uint32_t aux;
+                if (c & LEAF) {
+                    uint32_t k0, k1;
+                    runOf(c, k0, k1);
+                    b = AABB::Initial();
+                    for (uint32_t k = k0; k < k1; ++k) {
+                        const uint32_t fi = faces[k];
+                        b.Expand(trav::load_pos(positions, tri[3ull * fi]));
+                        b.Expand(trav::load_pos(positions, tri[3ull * fi + 1]));
+                        b.Expand(trav::load_pos(positions, tri[3ull * fi + 2]));
+                    }
+                    b.minPos = b.minPos - pad;
+                    b.maxPos = b.maxPos + pad;
+                    aux = parent;
+                } else {
+                    b = trav::load_node(nodes, c).box;
+                    const f3 e = b.maxPos - b.minPos;
+                    aux = __float_as_uint(e.x * e.y + e.y * e.z + e.z * e.x);
                 }
+                uint32_t lo[3], hi[3];
+                for (int a = 0; a < 3; ++a) {
+                    lo[a] = static_cast<uint32_t>(fminf(fmaxf(floorf((b.minPos[a] - org[a]) * inv[a]) - 1.f, 0.f), 255.f));
+                    hi[a] = static_cast<uint32_t>(fmaxf(fminf(ceilf((b.maxPos[a] - org[a]) * inv[a]) + 1.f, 255.f), 0.f));
+                }
+                s_q[j][tid] = make_uint2(lo[0] | (lo[1] << 8) | (lo[2] << 16) | (hi[0] << 24), hi[1] | (hi[2] << 8));
+                s_ref[j][tid] = c;
+                s_aux[j][tid] = aux;
+            };
+            put(0, me.lft, n);
+            cN = 1;
+            if (!(me.lft == me.rht && (me.lft & LEAF))) { // a single-leaf tree names its leaf twice
+                put(1, me.rht, n);
+                cN = 2;
+            }
+            while (cN < 8) {
+                int pick = -1;
+                float bestArea = -1.f;
+                for (int j = 0; j < cN; ++j)
+                    if (!(s_ref[j][tid] & LEAF)) {
+                        const float a = __uint_as_float(s_aux[j][tid]);
+                        if (!(a <= bestArea)) { // also takes a NaN area: every subtree can be opened
+                            bestArea = a;
+                            pick = j;
+                        }
+                    }
+                if (pick < 0)
+                    break;
+                const uint32_t c = s_ref[pick][tid];
+                const uint2 ch = *reinterpret_cast<const uint2 *>(nodes + c);
+                put(pick, ch.x, c);
+                put(cN, ch.y, c);
+                ++cN;
+            }
+            // slot = octant of the child's centre around the node's centre, nearest free one
+            uint32_t used = 0;
+            for (int j = 0; j < cN; ++j) {
+                const uint2 q = s_q[j][tid];
+                // (centre of the slot - centre of the node) * 2, in world units
+                const float dx = ldexpf(static_cast<float>((q.x & 0xffu) + (q.x >> 24)) - extQ.x, ex[0]);
+                const float dy = ldexpf(static_cast<float>(((q.x >> 8) & 0xffu) + (q.y & 0xffu)) - extQ.y, ex[1]);
+                const float dz = ldexpf(static_cast<float>(((q.x >> 16) & 0xffu) + ((q.y >> 8) & 0xffu)) - extQ.z, ex[2]);
+                int bestS = 0;
+                float bestScore = -__builtin_inff();
+                for (int sl = 0; sl < 8; ++sl) {
+                    if ((used >> sl) & 1u)
+                        continue;
+                    const float score = ((sl & 1) ? dx : -dx) + ((sl & 2) ? dy : -dy) + ((sl & 4) ? dz : -dz);
+                    if (!(score <= bestScore)) {
+                        bestScore = score;
+                        bestS = sl;
+                    }
+                }
+                used |= 1u << bestS;
+                childOf = (childOf & ~(0xFu << (4 * bestS))) | (static_cast<uint32_t>(j) << (4 * bestS));
+            }
+            for (int sl = 0; sl < 8; ++sl) {
+                const uint32_t j = (childOf >> (4 * sl)) & 0xFu;
+                if (j == 0xFu)
+                    continue;
+                const uint32_t ref = s_ref[j][tid];
+                if (ref & LEAF) {
+                    uint32_t k0, k1;
+                    runOf(ref, k0, k1);
+                    leafMask |= 1u << sl;
+                    ct += k1 - k0;
+                } else
+                    imask |= 1u << sl;
+            }
+            ci = __popc(imask);
+        }
+        // one reservation per wave
+        uint32_t ciIncl = ci, ctIncl = ct;
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t a = __shfl_up(ciIncl, o, 64), b = __shfl_up(ctIncl, o, 64);
+            if (lane >= o) {
+                ciIncl += a;
+                ctIncl += b;
             }
         }
-    }
-    AABB u = AABB::Initial();
-    for (int i = 0; i < 4; ++i)
-        if (slot[i].child != EMPTY)
-            u.Expand(slot[i].box);
-    Node4 w;
-    for (int a = 0; a < 3; ++a) {
-        const float ext = u.maxPos[a] - u.minPos[a];
-        const float r = ext / 253.f;
-        int e = r > 0.f ? ilogbf(r) + 1 : -100; // 2^e > ext / 253: offsets stay below 254
-        e = e < -100 ? -100 : (e > 100 ? 100 : e);
-        const float inv = ldexpf(1.f, -e);
-        w.origin[a] = u.minPos[a];
-        w.exp[a] = static_cast<int8_t>(e);
-        for (int i = 0; i < 4; ++i) {
-            float lo = 255.f, hi = 0.f;
-            if (slot[i].child != EMPTY) {
-                lo = fmaxf(floorf((slot[i].box.minPos[a] - u.minPos[a]) * inv) - 1.f, 0.f);
-                hi = fminf(ceilf((slot[i].box.maxPos[a] - u.minPos[a]) * inv) + 1.f, 255.f);
-            }
-            w.q[2 * a][i] = static_cast<uint8_t>(lo);
-            w.q[2 * a + 1][i] = static_cast<uint8_t>(hi);
+        uint32_t childBase = 0, triBase = 0;
+        if (lane == 63) {
+            if (ciIncl)
+                childBase = atomicAdd(&ctl->wideCount, ciIncl);
+            if (ctIncl)
+                triBase = atomicAdd(&ctl->triCount, ctIncl);
         }
-    }
-    w.pad = 0;
-    for (int i = 0; i < 4; ++i) {
-        w.child[i] = slot[i].child;
-        w.cnt[i] = static_cast<uint16_t>(slot[i].cnt < CNT_LONG ? slot[i].cnt : CNT_LONG);
-    }
-    uint4 *o = reinterpret_cast<uint4 *>(out + n);
-    const uint4 *src = reinterpret_cast<const uint4 *>(&w);
+        childBase = __shfl(childBase, 63, 64) + (ciIncl - ci);
+        triBase = __shfl(triBase, 63, 64) + (ctIncl - ct);
+        if (!valid)
+            continue;
+
+        Wide8 rec;
+        for (int a = 0; a < 3; ++a) {
+            rec.origin[a] = org[a];
+            rec.exp[a] = static_cast<int8_t>(ex[a]);
+        }
+        rec.imask = static_cast<uint8_t>(imask);
+        rec.childBase = childBase;
+        rec.triBase = triBase;
+        rec.leafMask = leafMask | (ct > 255u ? LONG_RUN : 0u);
+        rec.triTotal = ct;
+        uint32_t rank = 0, run = 0;
+        for (int sl = 0; sl < 8; ++sl) {
+            rec.off[sl] = rec.cnt[sl] = 0;
+            const uint32_t j = (childOf >> (4 * sl)) & 0xFu;
+            if (j == 0xFu) { // an empty slot cannot be hit
+                rec.q[0][sl] = rec.q[2][sl] = rec.q[4][sl] = 255;
+                rec.q[1][sl] = rec.q[3][sl] = rec.q[5][sl] = 0;
+                continue;
+            }
+            const uint2 q = s_q[j][tid];
+            rec.q[0][sl] = static_cast<uint8_t>(q.x), rec.q[1][sl] = static_cast<uint8_t>(q.x >> 24);
+            rec.q[2][sl] = static_cast<uint8_t>(q.x >> 8), rec.q[3][sl] = static_cast<uint8_t>(q.y);
+            rec.q[4][sl] = static_cast<uint8_t>(q.x >> 16), rec.q[5][sl] = static_cast<uint8_t>(q.y >> 8);
+            const uint32_t ref = s_ref[j][tid];
+            if (!(ref & LEAF)) {
+                rootOf[childBase + rank] = ref;
+                ++rank;
+                continue;
+            }
+            uint32_t k0, k1;
+            runOf(ref, k0, k1);
+            rec.off[sl] = static_cast<uint8_t>(run < 255u ? run : 255u);
+            rec.cnt[sl] = static_cast<uint8_t>(k1 - k0 < 255u ? k1 - k0 : 255u);
+            const uint32_t parent = s_aux[j][tid];
+            for (uint32_t k = k0; k < k1; ++k, ++run) {
+                const uint32_t fi = faces[k];
+                const f3 a = trav::load_pos(positions, tri[3ull * fi]);
+                const f3 b = trav::load_pos(positions, tri[3ull * fi + 1]);
+                const f3 c = trav::load_pos(positions, tri[3ull * fi + 2]);
+                uint4 *o = reinterpret_cast<uint4 *>(recs + triBase + run);
+                o[0] = make_uint4(__float_as_uint(a.x), __float_as_uint(a.y), __float_as_uint(a.z), fi);
+                o[1] = make_uint4(__float_as_uint(b.x), __float_as_uint(b.y), __float_as_uint(b.z), parent);
+                o[2] = make_uint4(__float_as_uint(c.x), __float_as_uint(c.y), __float_as_uint(c.z), k);
+            }
+        }
+        for (int i = 0; i < 8; ++i)
+            rec.spare[i] = 0;
+        uint4 *o = reinterpret_cast<uint4 *>(out + w);
+        const uint4 *src = reinterpret_cast<const uint4 *>(&rec);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-        o[i] = src[i];
+        for (int i = 0; i < 8; ++i)
+            o[i] = src[i];
+    }
 }
 
 // ---- ray ordering ---------------------------------------------------------------------------------
@@ -276,17 +420,17 @@ __global__ __launch_bounds__(THREADS) void ray_keys_kernel(const Header *__restr
 
 // ---- traversal ------------------------------------------------------------------------------------
 
-constexpr int STACK_DEPTH = 48; // <= 3 pushes per visited record, <= 15 records deep (tree depth <= 30)
+constexpr int STACK_DEPTH = 48; // <= 1 push per visited record, <= MAX_LEVELS records deep
 constexpr int LDS_DEPTH = 20;   // entries kept in LDS; deeper ones (rare) live in the workspace
-constexpr int REFILL_BELOW = 40;
-constexpr int PARK_MIN = 16; // run the triangle code once this many lanes wait for it ...
-constexpr int STEP_MIN = 24; // ... or fewer than this many lanes can still step
 constexpr uint32_t MAX_GRID = 1280; // 30 KB of LDS and < 96 VGPRs: five workgroups per CU
 // A product (b - o) * (1 / d) is within 3 * 2^-24 of the reference's fl((b - o) / d) (one rounding
 // each in 1 / d, the product, and the quotient it stands for); min / max keep the bound.
 constexpr float SLAB_REL = 1e-6f, SLAB_ABS = 1e-30f;
+constexpr float SLAB_SHRINK = 1.f - 1e-6f; // the same margin as a factor on the entry distance
 
 __device__ __forceinline__ float4 ld4(const char *p) { return *reinterpret_cast<const float4 *>(p); }
+
+typedef float v2f __attribute__((ext_vector_type(2)));
 
 struct RayState {
     f3 pos, dir, inv;
@@ -389,18 +533,25 @@ __device__ __forceinline__ float hit_watertight(const Shear &s, f3 org, f3 v0, f
     return t;
 }
 
+struct Hit8 {
+    float t, bx, by;
+    uint32_t fi; // face index, 0xFFFFFFFF = miss
+    uint32_t k;  // position in the sorted face order: the smaller one wins among equal t
+    uint32_t w;  // its TriRec
+};
+
 template <bool COUNT, bool WATERTIGHT>
 __device__ __forceinline__ void test_run(const TriRec *__restrict__ recs,
                                          const kk_lbvh_node *__restrict__ nodes,
                                          const uint32_t *__restrict__ parents, const RayState &r,
-                                         uint32_t mode, uint32_t k0, uint32_t n, trav::Hit &best,
+                                         uint32_t mode, uint32_t w0, uint32_t n, Hit8 &best,
                                          uint32_t &triTests) {
     const Ray ray{r.pos, r.dir};
     Shear shear{};
     if (WATERTIGHT && n != 0u)
         shear = make_shear(r.dir);
-    for (uint32_t k = k0; k < k0 + n; ++k) {
-        const uint4 *p = reinterpret_cast<const uint4 *>(recs + k);
+    for (uint32_t w = w0; w < w0 + n; ++w) {
+        const uint4 *p = reinterpret_cast<const uint4 *>(recs + w);
         const uint4 a = p[0], b = p[1], c = p[2];
         float bx = 0.f, by = 0.f;
         const f3 v0 = F3(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z));
@@ -410,57 +561,52 @@ __device__ __forceinline__ void test_run(const TriRec *__restrict__ recs,
                                    : HitTriangle(ray, v0, v1, v2, bx, by);
         if (COUNT)
             ++triTests;
-        if (t >= 0.f && (t < best.t || (t == best.t && k < best.k))) {
+        if (t >= 0.f && (t < best.t || (t == best.t && c.w < best.k))) {
             if (mode == MODE_FAST || (mode == MODE_CAREFUL ? passes_parent(nodes, b.w, r)
                                                            : passes_chain(nodes, parents, b.w, r))) {
                 best.t = t;
                 best.bx = bx;
                 best.by = by;
                 best.fi = a.w;
-                best.k = k;
+                best.k = c.w;
+                best.w = w;
             }
         }
     }
 }
 
-// compare-exchange of (key, id) pairs, ascending by key
-__device__ __forceinline__ void cswap(float &ka, uint32_t &ia, float &kb, uint32_t &ib) {
-    const bool sw = kb < ka;
-    const float k0 = sw ? kb : ka, k1 = sw ? ka : kb;
-    const uint32_t i0 = sw ? ib : ia, i1 = sw ? ia : ib;
-    ka = k0, kb = k1, ia = i0, ib = i1;
-}
-
 // Persistent wave64 workgroups pull rays (in sorted order) from a global counter. Per iteration every
-// lane is at the same place in the code: (A) lanes that need a node pop one stack entry, (B) lanes
-// with a node visit it, (C) when enough lanes have parked leaf triangles (or too few can still step)
-// the parked lanes test them. A finished ray waits until the wave refills: then all finished lanes
-// check their final hit against its leaf's parent box, write their result (or start the ray again
-// in careful mode if the check fails) and take new rays with one ballot + one atomic per wave.
+// lane is at the same place in the code: (A) lanes without a node take the next child of their current
+// group (or pop a group), (B) lanes with a node visit it, (C) when enough lanes have parked leaf
+// triangles (or too few can still step) the parked lanes test them. A group is what one visit found:
+// the node's childBase, its internal-slot mask and the hit slots still to be entered, kept in
+// front-to-back order of the ray's octant, so a visit pushes at most one stack entry. A finished ray
+// waits until the wave refills: then all finished lanes check their final hit against its leaf's
+// parent box, write their result (or start the ray again in careful mode if the check fails) and take
+// new rays with one ballot + one atomic per wave.
 //
 // Taking a better triangle hit without checking its parent box first is safe: the limit that prunes
 // the walk is never below the final t, so nothing closer is skipped; if the final hit itself fails
 // the check, the lane walks the ray again with every hit checked as it is taken.
 template <bool COUNT, bool WATERTIGHT>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(5, 5))) void closest_hit_accel_kernel(
-    const Header *__restrict__ hdr, const Node4 *__restrict__ node4, const TriRec *__restrict__ recs,
+    const Header *__restrict__ hdr, const Wide8 *__restrict__ wide, const TriRec *__restrict__ recs,
     const float *__restrict__ rays, const uint32_t *__restrict__ order, uint32_t rayNum,
     float *__restrict__ tOut, float *__restrict__ baryOut, uint32_t *__restrict__ primOut,
     uint32_t *rayCounter, const uint32_t *__restrict__ parents,
-    uint2 *__restrict__ spill, unsigned long long *counters) {
-    // nodes waiting to be visited: node index + entry distance cut to its upper 16 bits (a lower
-    // bound of a non-negative float, so the test on pop can only keep more)
-    __shared__ uint32_t s_node[LDS_DEPTH * THREADS];
-    __shared__ unsigned short s_enter[LDS_DEPTH * THREADS];
+    uint2 *__restrict__ spill, unsigned long long *counters, int PARK_MIN, int STEP_MIN, int REFILL_BELOW) {
+    // groups waiting to be entered: childBase + (pending slots | internal-slot mask << 8)
+    __shared__ uint32_t s_base[LDS_DEPTH * THREADS];
+    __shared__ unsigned short s_bits[LDS_DEPTH * THREADS];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    uint32_t *stNode = s_node + tid;
-    unsigned short *stEnter = s_enter + tid;
+    uint32_t *stBase = s_base + tid;
+    unsigned short *stBits = s_bits + tid;
     const unsigned long long lanesBelow = (1ull << lane) - 1ull;
     const size_t spillStride = static_cast<size_t>(gridDim.x) * THREADS;
     uint2 *mySpill = spill + static_cast<size_t>(blockIdx.x) * THREADS + tid;
     const kk_lbvh_node *nodes = hdr->nodes;
-    const char *node4Bytes = reinterpret_cast<const char *>(node4);
+    const char *wideBytes = reinterpret_cast<const char *>(wide);
 
     AABB rootBox;
     rootBox.minPos = {hdr->rootBox[0], hdr->rootBox[1], hdr->rootBox[2]};
@@ -472,23 +618,29 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(5, 5)))
     uint32_t rayIdx = 0;
     RayState ray;
     bool negX = false, negY = false, negZ = false; // which of min / max is the near plane
-    uint32_t cur = 0;                        // node to visit next
-    bool needNode = false; // cur is used up: take the next node from the stack
-    uint32_t mode = MODE_FAST; // how hits of this ray are checked (see test_run)
+    uint32_t oct = 0;                              // negX | negY << 1 | negZ << 2
+    uint32_t cur = 0;                              // node to visit next
+    bool have = false;                             // cur is valid
+    uint32_t grpBase = 0, grpBits = 0;             // current group (see above)
+    uint32_t mode = MODE_FAST;                     // how hits of this ray are checked (see test_run)
     int sp = 0;
-    uint32_t pendK0 = 0, pendC0 = 0, pendK1 = 0, pendC1 = 0;
-    trav::Hit best;
+    uint32_t pendW = 0, pendC = 0; // parked triangles
+    Hit8 best;
     uint32_t nodeVisits = 0, triTests = 0;
     unsigned long long totNodes = 0, totTris = 0, totRays = 0;
+    unsigned long long dbgIters = 0, dbgVisitLanes = 0, dbgTriRuns = 0, dbgTriLanes = 0, dbgTriTrips = 0;
 
-    auto push = [&](uint32_t node, float enter) {
-        const uint32_t bits = __float_as_uint(enter) >> 16;
-        if (sp < LDS_DEPTH) {
-            stNode[sp * THREADS] = node;
-            stEnter[sp * THREADS] = static_cast<unsigned short>(bits);
-        } else if (sp < STACK_DEPTH)
-            mySpill[(sp - LDS_DEPTH) * spillStride] = make_uint2(node, bits);
-        ++sp;
+    auto restart = [&]() {
+        best.t = FloatMax;
+        best.bx = best.by = 0.f;
+        best.fi = best.k = best.w = 0xFFFFFFFFu;
+        sp = 0;
+        pendC = 0u;
+        // a group that holds just the root: slot 0 of a node whose only internal slot is slot 0
+        grpBase = 0u;
+        grpBits = (1u << (0u ^ oct)) | (1u << 8);
+        have = false;
+        active = true;
     };
 
     while (true) {
@@ -496,7 +648,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(5, 5)))
         if (finished) {
             bool ok = true;
             if (best.fi != 0xFFFFFFFFu && mode == MODE_FAST)
-                ok = passes_parent(nodes, recs[best.k].parent, ray);
+                ok = passes_parent(nodes, recs[best.w].parent, ray);
             finished = false;
             if (ok) {
                 tOut[rayIdx] = best.t;
@@ -510,14 +662,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(5, 5)))
                 }
             } else { // walk this ray again, checking every hit when it is taken
                 mode = MODE_CAREFUL;
-                best.t = FloatMax;
-                best.bx = best.by = 0.f;
-                best.fi = best.k = 0xFFFFFFFFu;
-                cur = 0;
-                sp = 0;
-                pendC0 = pendC1 = 0u;
-                needNode = false;
-                active = true;
+                restart();
             }
         }
         const unsigned long long idleMask = __ballot(!active);
@@ -552,25 +697,17 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(5, 5)))
                         if (!(fabsf(ray.inv.z) < 1e18f))
                             ray.inv.z = copysignf(1e18f, ray.dir.z);
                     }
-                    {
-                        negX = ray.inv.x < 0.f;
-                        negY = ray.inv.y < 0.f;
-                        negZ = ray.inv.z < 0.f;
-                        nodeVisits = triTests = 0;
-                        best.t = FloatMax;
-                        best.bx = best.by = 0.f;
-                        best.fi = best.k = 0xFFFFFFFFu;
-                        float tEnter, tExit;
-                        HitAABB(Ray{ray.pos, ray.dir}, rootBox, tEnter, tExit);
-                        cur = 0;
-                        sp = 0;
-                        pendC0 = pendC1 = 0u;
-                        needNode = false;
-                        active = true;
-                        if (tEnter > tExit) { // misses the scene: retire at the next refill
-                            active = false;
-                            finished = true;
-                        }
+                    negX = ray.inv.x < 0.f;
+                    negY = ray.inv.y < 0.f;
+                    negZ = ray.inv.z < 0.f;
+                    oct = (negX ? 1u : 0u) | (negY ? 2u : 0u) | (negZ ? 4u : 0u);
+                    nodeVisits = triTests = 0;
+                    restart();
+                    float tEnter, tExit;
+                    HitAABB(Ray{ray.pos, ray.dir}, rootBox, tEnter, tExit);
+                    if (tEnter > tExit) { // misses the scene: retire at the next refill
+                        active = false;
+                        finished = true;
                     }
                 }
             }
@@ -583,114 +720,146 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(5, 5)))
 
         while (true) {
             const float limit = best.t + trav::CULL_SLACK * best.t;
-            // ---- (A) take the next node from the stack ---------------------------------------------
-            if (active && needNode && (pendC0 | pendC1) == 0u) {
-                if (sp > 0) {
-                    --sp;
-                    uint32_t node = 0, enterBits = 0x7f80u;
-                    if (sp < LDS_DEPTH) {
-                        node = stNode[sp * THREADS];
-                        enterBits = stEnter[sp * THREADS];
-                    } else if (sp < STACK_DEPTH) {
-                        const uint2 e = mySpill[(sp - LDS_DEPTH) * spillStride];
-                        node = e.x;
-                        enterBits = e.y;
+            // ---- (A) next node: from the current group, else from the stack ------------------------
+            if (active && !have && pendC == 0u) {
+                if ((grpBits & 0xffu) == 0u) {
+                    if (sp > 0) {
+                        --sp;
+                        if (sp < LDS_DEPTH) {
+                            grpBase = stBase[sp * THREADS];
+                            grpBits = stBits[sp * THREADS];
+                        } else if (sp < STACK_DEPTH) {
+                            const uint2 e = mySpill[(sp - LDS_DEPTH) * spillStride];
+                            grpBase = e.x;
+                            grpBits = e.y;
+                        }
+                    } else { // walk over
+                        active = false;
+                        finished = true;
                     }
-                    if (!(__uint_as_float(enterBits << 16) > limit)) {
-                        cur = node;
-                        needNode = false;
-                    }
-                } else { // walk over
-                    active = false;
-                    finished = true;
+                }
+                if ((grpBits & 0xffu) != 0u) {
+                    const uint32_t i = static_cast<uint32_t>(__ffs(static_cast<int>(grpBits))) - 1u;
+                    grpBits &= grpBits - 1u; // the lowest set bit is a pending slot
+                    const uint32_t slot = i ^ oct;
+                    cur = grpBase + __popc((grpBits >> 8) & ((1u << slot) - 1u));
+                    have = true;
                 }
             }
             // ---- (B) visit a node ------------------------------------------------------------------
-            const bool canStep = active && !needNode && (pendC0 | pendC1) == 0u;
-            if (canStep) {
-                const uint4 *rec = reinterpret_cast<const uint4 *>(node4Bytes + (static_cast<size_t>(cur) << 6));
-                const uint4 w0 = rec[0], w1 = rec[1], w2 = rec[2], w3 = rec[3];
+            if (COUNT) {
+                ++dbgIters;
+                dbgVisitLanes += __popcll(__ballot(have));
+            }
+            if (have) {
+                have = false;
+                const uint4 *rec = reinterpret_cast<const uint4 *>(wideBytes + (static_cast<size_t>(cur) << 7));
+                const uint4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3], r4 = rec[4], r5 = rec[5];
                 if (COUNT)
                     ++nodeVisits;
-                // plane distance = q * (2^exp / d) + (origin - o) / d
-                const float ax = ldexpf(ray.inv.x, static_cast<int>(static_cast<int8_t>(w0.w & 0xffu)));
-                const float ay = ldexpf(ray.inv.y, static_cast<int>(static_cast<int8_t>((w0.w >> 8) & 0xffu)));
-                const float az = ldexpf(ray.inv.z, static_cast<int>(static_cast<int8_t>((w0.w >> 16) & 0xffu)));
-                const float bx = (__uint_as_float(w0.x) - ray.pos.x) * ray.inv.x;
-                const float by = (__uint_as_float(w0.y) - ray.pos.y) * ray.inv.y;
-                const float bz = (__uint_as_float(w0.z) - ray.pos.z) * ray.inv.z;
-                // near / far plane bytes by the sign of the direction
-                const uint32_t qnx = negX ? w1.y : w1.x, qfx = negX ? w1.x : w1.y;
-                const uint32_t qny = negY ? w1.w : w1.z, qfy = negY ? w1.z : w1.w;
-                const uint32_t qnz = negZ ? w2.y : w2.x, qfz = negZ ? w2.x : w2.y;
-                const uint32_t child[4] = {w2.z, w2.w, w3.x, w3.y};
-                uint32_t cnt[4] = {w3.z & 0xffffu, w3.z >> 16, w3.w & 0xffffu, w3.w >> 16};
-                float key[4];
-                uint32_t leafCnt[4];
+                // plane distance = q * (2^exp / d) + (origin - o) / d; the "+ 0" turns a -0 offset into
+                // +0, so that no plane distance is -0 and a box that touches the origin is kept
+                const float ax = ldexpf(ray.inv.x, static_cast<int>(static_cast<int8_t>(r0.w & 0xffu)));
+                const float ay = ldexpf(ray.inv.y, static_cast<int>(static_cast<int8_t>((r0.w >> 8) & 0xffu)));
+                const float az = ldexpf(ray.inv.z, static_cast<int>(static_cast<int8_t>((r0.w >> 16) & 0xffu)));
+                const float bx = __builtin_fmaf(__uint_as_float(r0.x) - ray.pos.x, ray.inv.x, 0.f);
+                const float by = __builtin_fmaf(__uint_as_float(r0.y) - ray.pos.y, ray.inv.y, 0.f);
+                const float bz = __builtin_fmaf(__uint_as_float(r0.z) - ray.pos.z, ray.inv.z, 0.f);
+                const v2f ax2 = {ax, ax}, ay2 = {ay, ay}, az2 = {az, az};
+                const v2f bx2 = {bx, bx}, by2 = {by, by}, bz2 = {bz, bz};
+                // near / far plane bytes by the sign of the direction: [0] slots 0-3, [1] slots 4-7
+                const uint32_t qnx[2] = {negX ? r2.z : r2.x, negX ? r2.w : r2.y};
+                const uint32_t qfx[2] = {negX ? r2.x : r2.z, negX ? r2.y : r2.w};
+                const uint32_t qny[2] = {negY ? r3.z : r3.x, negY ? r3.w : r3.y};
+                const uint32_t qfy[2] = {negY ? r3.x : r3.z, negY ? r3.y : r3.w};
+                const uint32_t qnz[2] = {negZ ? r4.z : r4.x, negZ ? r4.w : r4.y};
+                const uint32_t qfz[2] = {negZ ? r4.x : r4.z, negZ ? r4.y : r4.w};
+                // A slot is kept unless it is missed beyond the rounding margin: the sign of
+                // exit - entry * (1 - margin) is shifted into `missed`, slot 7 first.
+                uint32_t missed = 0;
+                bool anyNoLimit = false;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float hnx = __builtin_fmaf(static_cast<float>((qnx >> (8 * i)) & 0xffu), ax, bx);
-                    const float hny = __builtin_fmaf(static_cast<float>((qny >> (8 * i)) & 0xffu), ay, by);
-                    const float hnz = __builtin_fmaf(static_cast<float>((qnz >> (8 * i)) & 0xffu), az, bz);
-                    const float hfx = __builtin_fmaf(static_cast<float>((qfx >> (8 * i)) & 0xffu), ax, bx);
-                    const float hfy = __builtin_fmaf(static_cast<float>((qfy >> (8 * i)) & 0xffu), ay, by);
-                    const float hfz = __builtin_fmaf(static_cast<float>((qfz >> (8 * i)) & 0xffu), az, bz);
-                    const float en = fmaxf(fmaxf(fmaxf(hnx, hny), hnz), 0.f);
-                    const float ex = fminf(fminf(hfx, hfy), hfz);
-                    // conservative: keep the slot unless the miss is beyond the rounding margin
-                    // (a NaN, possible only with overflowing stand-ins, keeps the slot)
-                    const bool hit = !(en > __builtin_fmaf(fabsf(ex), SLAB_REL, ex + SLAB_ABS)) &
-                                     !(en > limit) & (child[i] != EMPTY);
-                    const bool isLeaf = cnt[i] != 0u;
-                    if (hit & (cnt[i] == CNT_LONG)) // a very long run: its length is in its first record
-                        cnt[i] = recs[child[i] & LEAF_MASK].run;
-                    leafCnt[i] = (hit & isLeaf) ? cnt[i] : 0u;
-                    key[i] = (hit & !isLeaf) ? en : __builtin_inff();
+                for (int pr = 3; pr >= 0; --pr) {
+                    const int h = pr >> 1, sh = 16 * (pr & 1); // slots 2 pr and 2 pr + 1
+                    auto two = [&](uint32_t w) {
+                        v2f q;
+                        q.x = static_cast<float>((w >> sh) & 0xffu);
+                        q.y = static_cast<float>((w >> (sh + 8)) & 0xffu);
+                        return q;
+                    };
+                    const v2f hnx = __builtin_elementwise_fma(two(qnx[h]), ax2, bx2);
+                    const v2f hny = __builtin_elementwise_fma(two(qny[h]), ay2, by2);
+                    const v2f hnz = __builtin_elementwise_fma(two(qnz[h]), az2, bz2);
+                    const v2f hfx = __builtin_elementwise_fma(two(qfx[h]), ax2, bx2);
+                    const v2f hfy = __builtin_elementwise_fma(two(qfy[h]), ay2, by2);
+                    const v2f hfz = __builtin_elementwise_fma(two(qfz[h]), az2, bz2);
+                    if (COUNT) { // would the slots be hit without the distance limit?
+                        const float e1 = fmaxf(fmaxf(fmaxf(hnx.y, hny.y), hnz.y), 0.f), x1 = fminf(fminf(hfx.y, hfy.y), hfz.y);
+                        const float e0 = fmaxf(fmaxf(fmaxf(hnx.x, hny.x), hnz.x), 0.f), x0 = fminf(fminf(hfx.x, hfy.x), hfz.x);
+                        anyNoLimit |= !(e1 * SLAB_SHRINK > x1) || !(e0 * SLAB_SHRINK > x0);
+                    }
+                    const float en1 = fmaxf(fmaxf(fmaxf(hnx.y, hny.y), hnz.y), 0.f);
+                    const float ex1 = fminf(fminf(fminf(hfx.y, hfy.y), hfz.y), limit);
+                    const float en0 = fmaxf(fmaxf(fmaxf(hnx.x, hny.x), hnz.x), 0.f);
+                    const float ex0 = fminf(fminf(fminf(hfx.x, hfy.x), hfz.x), limit);
+                    missed = __builtin_amdgcn_alignbit(missed, __float_as_uint(__builtin_fmaf(-SLAB_SHRINK, en1, ex1)), 31);
+                    missed = __builtin_amdgcn_alignbit(missed, __float_as_uint(__builtin_fmaf(-SLAB_SHRINK, en0, ex0)), 31);
                 }
-                // leaf slots: park their triangles. Slots 0,1 (and 2,3) that are both leaves are
-                // neighbouring runs of the sorted order, so each pair parks one (first, count).
-                pendK0 = (leafCnt[0] ? child[0] : child[1]) & LEAF_MASK;
-                pendC0 = leafCnt[0] + leafCnt[1];
-                pendK1 = (leafCnt[2] ? child[2] : child[3]) & LEAF_MASK;
-                pendC1 = leafCnt[2] + leafCnt[3];
-                // internal slots: nearest first, the others stacked farthest first
-                uint32_t id[4] = {child[0], child[1], child[2], child[3]};
-                cswap(key[0], id[0], key[1], id[1]);
-                cswap(key[2], id[2], key[3], id[3]);
-                cswap(key[0], id[0], key[2], id[2]);
-                cswap(key[1], id[1], key[3], id[3]);
-                cswap(key[1], id[1], key[2], id[2]);
-                const float inf = __builtin_inff();
-                if (sp + 3 <= LDS_DEPTH) {
-                    // stores above the stack top are harmless: write all three, count the valid ones
-                    stNode[sp * THREADS] = id[3];
-                    stEnter[sp * THREADS] = static_cast<unsigned short>(__float_as_uint(key[3]) >> 16);
-                    sp += key[3] < inf;
-                    stNode[sp * THREADS] = id[2];
-                    stEnter[sp * THREADS] = static_cast<unsigned short>(__float_as_uint(key[2]) >> 16);
-                    sp += key[2] < inf;
-                    stNode[sp * THREADS] = id[1];
-                    stEnter[sp * THREADS] = static_cast<unsigned short>(__float_as_uint(key[1]) >> 16);
-                    sp += key[1] < inf;
-                } else {
-                    if (key[3] < inf)
-                        push(id[3], key[3]);
-                    if (key[2] < inf)
-                        push(id[2], key[2]);
-                    if (key[1] < inf)
-                        push(id[1], key[1]);
+                const uint32_t hits = ~missed;
+                const uint32_t imask = r0.w >> 24;
+                const uint32_t leafHits = hits & r1.z & 0xffu;
+                uint32_t inner = hits & imask;
+                if (COUNT && (leafHits | inner) == 0u) {
+                    ++dbgTriTrips; // visits that found nothing
+                    if (anyNoLimit)
+                        dbgTriTrips += 1ull << 32; // ... because of the distance limit
                 }
-                cur = id[0];
-                needNode = !(key[0] < inf);
+                if (leafHits != 0u) {
+                    // park the triangles from the first to the last leaf slot that was hit
+                    if (r1.z & LONG_RUN) {
+                        pendW = r1.y;
+                        pendC = r1.w;
+                    } else {
+                        const uint32_t first = static_cast<uint32_t>(__ffs(static_cast<int>(leafHits))) - 1u;
+                        const uint32_t last = 31u - static_cast<uint32_t>(__clz(static_cast<int>(leafHits)));
+                        const unsigned long long offs = (static_cast<unsigned long long>(r5.y) << 32) | r5.x;
+                        const unsigned long long cnts = (static_cast<unsigned long long>(r5.w) << 32) | r5.z;
+                        const uint32_t b0 = static_cast<uint32_t>(offs >> (8u * first)) & 0xffu;
+                        const uint32_t b1 = (static_cast<uint32_t>(offs >> (8u * last)) & 0xffu) +
+                                            (static_cast<uint32_t>(cnts >> (8u * last)) & 0xffu);
+                        pendW = r1.y + b0;
+                        pendC = b1 - b0;
+                    }
+                }
+                if (inner != 0u) {
+                    // bit i of the group = slot i ^ oct: ascending bits run front to back
+                    inner = (oct & 1u) ? (((inner & 0xAAu) >> 1) | ((inner & 0x55u) << 1)) : inner;
+                    inner = (oct & 2u) ? (((inner & 0xCCu) >> 2) | ((inner & 0x33u) << 2)) : inner;
+                    inner = (oct & 4u) ? (((inner & 0xF0u) >> 4) | ((inner & 0x0Fu) << 4)) : inner;
+                    if ((grpBits & 0xffu) != 0u) {
+                        if (sp < LDS_DEPTH) {
+                            stBase[sp * THREADS] = grpBase;
+                            stBits[sp * THREADS] = static_cast<unsigned short>(grpBits);
+                        } else if (sp < STACK_DEPTH)
+                            mySpill[(sp - LDS_DEPTH) * spillStride] = make_uint2(grpBase, grpBits);
+                        ++sp;
+                    }
+                    grpBase = r1.x;
+                    grpBits = inner | (imask << 8);
+                }
             }
             // ---- (C) triangle phase, when it pays --------------------------------------------------
-            const int parked = __popcll(__ballot((pendC0 | pendC1) != 0u));
-            const int stepping = __popcll(__ballot(active && (pendC0 | pendC1) == 0u));
+            const int parked = __popcll(__ballot(pendC != 0u));
+            const int stepping = __popcll(__ballot(active && pendC == 0u));
             if (parked != 0 && (parked >= PARK_MIN || stepping < STEP_MIN)) {
-                if ((pendC0 | pendC1) != 0u) {
-                    test_run<COUNT, WATERTIGHT>(recs, nodes, parents, ray, mode, pendK0, pendC0, best, triTests);
-                    test_run<COUNT, WATERTIGHT>(recs, nodes, parents, ray, mode, pendK1, pendC1, best, triTests);
-                    pendC0 = pendC1 = 0u;
+                if (COUNT) {
+                    ++dbgTriRuns;
+                    dbgTriLanes += parked;
+                }
+                if (pendC != 0u) { // one triangle per lane and phase: lanes with longer runs stay parked
+                    test_run<COUNT, WATERTIGHT>(recs, nodes, parents, ray, mode, pendW, 1u, best, triTests);
+                    ++pendW;
+                    --pendC;
                 }
             }
             const int alive = __popcll(__ballot(active));
@@ -709,7 +878,17 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(5, 5)))
             atomicAdd(&counters[0], totNodes);
             atomicAdd(&counters[1], totTris);
             atomicAdd(&counters[2], totRays);
+            // per-wave figures: inner-loop passes, lanes that visited a node, triangle phases, lanes in
+            // them, and their longest runs
+            atomicAdd(&counters[3], dbgIters);
+            atomicAdd(&counters[4], dbgVisitLanes);
+            atomicAdd(&counters[5], dbgTriRuns);
+            atomicAdd(&counters[6], dbgTriLanes);
         }
+        for (int o = 32; o > 0; o >>= 1)
+            dbgTriTrips += __shfl_xor(dbgTriTrips, o, 64);
+        if (lane == 0)
+            atomicAdd(&counters[7], dbgTriTrips);
     }
 }
 
@@ -754,14 +933,27 @@ extern "C" int kk_trace_accel_build(const kk_lbvh_device_data *d_lbvh, const flo
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     char *b = static_cast<char *>(d_accel);
     const uint32_t nodeNum = compacted_face_num > 1 ? compacted_face_num - 1 : 1;
-    auto *recs = reinterpret_cast<TriRec *>(b + l.tris);
-    pack_tris_kernel<<<div_up(face_num, THREADS), THREADS, 0, stream>>>(d_lbvh, d_positions,
-                                                                        d_face_pos_idx, recs, face_num);
+    auto *hdr = reinterpret_cast<Header *>(b + l.header);
+    auto *ctl = reinterpret_cast<BuildCtl *>(b + l.ctl);
+    auto *rootOf = reinterpret_cast<uint32_t *>(b + l.rootOf);
+    init_build_kernel<<<1, 1, 0, stream>>>(d_lbvh, hdr, ctl, rootOf, nodeNum);
     KK_LAUNCH_CHECK();
-    make_node4_kernel<<<div_up(nodeNum, THREADS), THREADS, 0, stream>>>(
-        d_lbvh, recs, reinterpret_cast<Node4 *>(b + l.nodes),
-        reinterpret_cast<uint32_t *>(b + l.parents), reinterpret_cast<Header *>(b + l.header), nodeNum);
+    parents_kernel<<<div_up(nodeNum, THREADS), THREADS, 0, stream>>>(
+        d_lbvh, reinterpret_cast<uint32_t *>(b + l.parents), nodeNum);
     KK_LAUNCH_CHECK();
+    uint32_t grid = div_up(nodeNum, BT);
+    if (grid > 2048)
+        grid = 2048;
+    for (int level = 0; level < MAX_LEVELS; ++level) {
+        // level l has at most 8^l nodes
+        const uint32_t g = level < 7 ? (grid < div_up(1u << (3 * level), BT) ? grid : div_up(1u << (3 * level), BT)) : grid;
+        collapse_level_kernel<<<g, BT, 0, stream>>>(d_lbvh, d_positions, d_face_pos_idx,
+                                                    reinterpret_cast<Wide8 *>(b + l.nodes),
+                                                    reinterpret_cast<TriRec *>(b + l.tris), rootOf, ctl, level);
+        KK_LAUNCH_CHECK();
+        close_level_kernel<<<1, 1, 0, stream>>>(ctl, hdr, level);
+        KK_LAUNCH_CHECK();
+    }
     return KK_OK;
 }
 
@@ -791,7 +983,7 @@ extern "C" int kk_closest_hit_accel(const void *d_accel, uint32_t face_num,
     const Layout l = layout(face_num, compacted_face_num);
     const char *ab = static_cast<const char *>(d_accel);
     const auto *hdr = reinterpret_cast<const Header *>(ab + l.header);
-    const auto *node4 = reinterpret_cast<const Node4 *>(ab + l.nodes);
+    const auto *wide = reinterpret_cast<const Wide8 *>(ab + l.nodes);
     const auto *recs = reinterpret_cast<const TriRec *>(ab + l.tris);
     char *b = static_cast<char *>(d_workspace);
     uint32_t *rayCounter = reinterpret_cast<uint32_t *>(b + w.counter);
@@ -818,10 +1010,13 @@ extern "C" int kk_closest_hit_accel(const void *d_accel, uint32_t face_num,
     uint2 *spill = reinterpret_cast<uint2 *>(b + w.spill);
     const auto *parents = reinterpret_cast<const uint32_t *>(ab + l.parents);
     const bool wt = (flags & KK_TRACE_WATERTIGHT) != 0;
+    int tune[3] = {16, 24, 40};
+    if (const char *e = getenv("KK_TUNE"))
+        sscanf(e, "%d,%d,%d", &tune[0], &tune[1], &tune[2]);
 #define KK_LAUNCH_TRACE(COUNT, WT)                                                                 \
     closest_hit_accel_kernel<COUNT, WT><<<grid, THREADS, 0, stream>>>(                              \
-        hdr, node4, recs, d_rays, order, ray_num, d_t, d_bary, d_prim, rayCounter, parents, spill,  \
-        d_counters)
+        hdr, wide, recs, d_rays, order, ray_num, d_t, d_bary, d_prim, rayCounter, parents, spill,  \
+        d_counters, tune[0], tune[1], tune[2])
     if (d_counters) {
         if (wt)
             KK_LAUNCH_TRACE(true, true);

@@ -107,6 +107,8 @@ class DepthBoxVDB:
         n_slots = slots[0] * slots[1] * slots[2]
         stream = _lib.current_stream_ptr()
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        import time
+        tw = [time.perf_counter()]
         with torch.cuda.device(dev):
             d_valid = torch.empty(n_slots, dtype=torch.int32, device=dev)
             ev[0].record()
@@ -115,27 +117,34 @@ class DepthBoxVDB:
                 d_valid.data_ptr(), stream), "kk_vdb_classify")
             ev[1].record()
             h_valid = d_valid.cpu().numpy().view(np.uint32)
+            tw.append(time.perf_counter())
             plan = _lib.VdbPlan()
             _lib.check(l.kk_vdb_plan_build(vol.dx, vol.dy, vol.dz, l2, int(apron_wid), int(use_depth_box),
                                            h_valid.ctypes.data_as(C.c_void_p), C.byref(plan)),
                        "kk_vdb_plan_build")
+            tw.append(time.perf_counter())
             nodes = np.zeros(int(plan.node_num), NODE_DTYPE)
             children = np.zeros(int(plan.child_num), np.uint32)
             amap = np.zeros(int(plan.atlas_map_num), np.uint32)
             _lib.check(l.kk_vdb_wire(C.byref(plan), h_valid.ctypes.data_as(C.c_void_p),
                                      nodes.ctypes.data_as(C.c_void_p), children.ctypes.data_as(C.c_void_p),
                                      amap.ctypes.data_as(C.c_void_p)), "kk_vdb_wire")
+            tw.append(time.perf_counter())
             self.d_node_pools = torch.from_numpy(nodes.view(np.uint8)).to(dev)
             self.d_child_pools = torch.from_numpy(children.view(np.int32)).to(dev)
             self.d_atlas_brick_to_node = torch.from_numpy(amap.view(np.int32)).to(dev)
             self.d_atlas = torch.empty(int(plan.atlas_voxels) * vol.itemsize, dtype=torch.uint8, device=dev)
+            tw.append(time.perf_counter())
             ev[2].record()
             _lib.check(getattr(l, f"kk_vdb_fill_atlas_{sfx}")(
                 vol.tensor.data_ptr(), vol.dx, vol.dy, vol.dz, C.byref(plan), self.d_node_pools.data_ptr(),
                 rng_p, rng.shape[0], self.d_atlas.data_ptr(), stream), "kk_vdb_fill_atlas")
             ev[3].record()
             torch.cuda.synchronize(dev)
+        tw.append(time.perf_counter())
         self.timings = {"classify_ms": ev[0].elapsed_time(ev[1]), "fill_atlas_ms": ev[2].elapsed_time(ev[3])}
+        for k, name in enumerate(("classify_and_readback", "plan", "wire", "upload_alloc", "fill_and_sync")):
+            self.timings["host_" + name + "_ms"] = (tw[k + 1] - tw[k]) * 1e3
         self.plan, self.voxel_bytes = plan, vol.itemsize
         self.host_nodes, self.host_children, self.host_atlas_map = nodes, children, amap
         dd = _lib.VdbDeviceData()

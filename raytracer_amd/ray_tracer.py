@@ -36,7 +36,7 @@ def closest_hit(lbvh: LBVH, rays, count: bool = False, out=None, layout: str = "
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     else:
         t, bary, prim, ws = out
-    counters = torch.zeros(4, dtype=torch.int64, device=dev) if count else None
+    counters = torch.zeros(8, dtype=torch.int64, device=dev) if count else None
     with torch.cuda.device(dev):
         if layout == "trace":
             accel = lbvh.trace_accel()
@@ -58,7 +58,8 @@ def closest_hit(lbvh: LBVH, rays, count: bool = False, out=None, layout: str = "
                                         _lib.current_stream_ptr()), "kk_closest_hit")
     if count:
         c = counters.cpu().numpy()
-        return t, bary, prim, {"node_fetches": int(c[0]), "tri_tests": int(c[1]), "rays": int(c[2])}
+        return t, bary, prim, {"node_fetches": int(c[0]), "tri_tests": int(c[1]), "rays": int(c[2]),
+                               "wave_stats": [int(x) for x in c[3:8]]}
     return t, bary, prim
 
 

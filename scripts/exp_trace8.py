@@ -1,0 +1,39 @@
+"""Closest hit on the benchmark workload: time, work counters and per-wave utilisation figures."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from raytracer_amd import synthetic as syn
+from raytracer_amd.lbvh import LBVH
+from raytracer_amd.ray_tracer import closest_hit
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
+R = int(sys.argv[2]) if len(sys.argv) > 2 else 2_097_152
+dev = "cuda:0"
+pos, tri = syn.triangle_soup(N)
+bvh = LBVH(dev)
+bvh.BuildFrom(torch.from_numpy(pos), torch.from_numpy(tri.view(np.int32)))
+rays = torch.from_numpy(syn.incoherent_rays(R)).to(dev)
+
+
+def timeit(fn, n=10):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+print("accel build: %.3f ms" % timeit(lambda: bvh.trace_accel(rebuild=True), 3), flush=True)
+hdr = bvh.trace_accel()[:64].view(torch.int32).cpu().numpy()
+print("wide nodes:", int(hdr[10]), "of", int(hdr[7]), "binary nodes")
+got = closest_hit(bvh, rays, count=True)
+c = got[3]
+it, vl, tr, tl, tt = c["wave_stats"]
+print({k: round(v / R, 2) for k, v in c.items() if k != "wave_stats"})
+print(f"wave passes {it}, visit lanes/pass {vl / it:.1f}, tri phases {tr} ({tr / it:.3f}/pass), "
+      f"lanes/tri phase {tl / max(tr, 1):.1f}, empty visits/ray {(tt & 0xffffffff) / R:.2f}, of them by the limit {(tt >> 32) / R:.2f}")
+ms = timeit(lambda: closest_hit(bvh, rays))
+ms2 = timeit(lambda: closest_hit(bvh, rays, reuse_order=True))
+print(f"sorted: {ms:.3f} ms {R / ms / 1e3:.1f} Mrays/s; kernel only {ms2:.3f} ms {R / ms2 / 1e3:.1f} Mrays/s")
