@@ -179,16 +179,20 @@ def main():
         return
 
     # ---- roofline of the dominant kernel (closest_hit_accel_kernel) ---------------------------------
-    # algorithmic bytes per launch: 64 B per node record visited + 48 B per triangle record tested +
-    # 4 B order index + 24 B ray in + 16 B hit out, counted by the kernel's own work counters
-    alg_bytes = 128 * counters["node_fetches"] + 48 * counters["tri_tests"] + (4 + 24 + 16) * R
+    # algorithmic bytes per launch: the 96 B a visit reads of a 128-B node record + 48 B per triangle
+    # record tested + 4 B order index + 24 B ray in + 16 B hit out, from the kernel's own work counters
+    alg_bytes = 96 * counters["node_fetches"] + 48 * counters["tri_tests"] + (4 + 24 + 16) * R
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+    passes = max(counters["wave_passes"], 1)
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
                 "kernel": "closest_hit_accel_kernel", "avg_launch_ms": round(kernel_ms, 4),
                 "algorithmic_bytes_per_launch": int(alg_bytes),
                 "node_records_per_ray": round(counters["node_fetches"] / R, 2),
-                "tri_tests_per_ray": round(counters["tri_tests"] / R, 2)}
+                "tri_tests_per_ray": round(counters["tri_tests"] / R, 2),
+                "empty_visits_per_ray": round(counters["empty_visits"] / R, 2),
+                "lanes_visiting_per_wave_pass": round(counters["visit_lanes"] / passes, 1),
+                "lanes_per_triangle_phase": round(counters["tri_lanes"] / max(counters["tri_phases"], 1), 1)}
     pmc = os.path.join(ROOT, "profiles", "r01_closest_hit_pmc.json")
     if os.path.exists(pmc):
         try:

@@ -140,10 +140,13 @@ int kk_closest_hit(const kk_lbvh_device_data *d_lbvh, const float *d_positions,
 
 /* ---- trace-side layout of a built tree (no counterpart in the reference: its rayCastLBVH walks the
  * build's own arrays, src/ray_tracer/ray_tracer_render.cu:192-270). kk_trace_accel_build repacks the
- * binary tree kk_lbvh_build produced: one 64-byte record per internal node holding the ids and the
- * 8-bit quantised (outward-rounded) boxes of its four grandchildren (a leaf's box is the box of its
- * triangles grown by 1e-5 of the scene's largest coordinate), one 48-byte record per sorted triangle
- * (three vertices, face index, index of the leaf's parent node) and each node's parent index.
+ * binary tree kk_lbvh_build produced into 8-wide nodes: a 128-byte record (one L2 line) holds up to
+ * eight descendants of a binary node (the child with the largest box is opened until eight slots
+ * are filled) as 8-bit quantised, outward-rounded boxes; a slot is a subtree (its record sits at
+ * childBase + rank: children are contiguous) or a leaf (a leaf's box is the box of its triangles
+ * grown by 1e-5 of the scene's largest coordinate). Triangles are 48-byte records (three vertices,
+ * face index, the leaf's parent binary node, sorted position) stored contiguously per wide node.
+ * Each binary node's parent index is kept for rays with a zero direction component.
  * kk_closest_hit_accel gives the same (t, bary, prim) as kk_closest_hit: a triangle counts exactly
  * when the ray passes the reference's slab test of the leaf's parent box (which, boxes being exact
  * unions, implies the tests of all nodes above it; for rays with a zero direction component every
@@ -163,8 +166,10 @@ int kk_trace_accel_build(const kk_lbvh_device_data *d_lbvh, const float *d_posit
                          const uint32_t *d_face_pos_idx, uint32_t face_num,
                          uint32_t compacted_face_num, void *d_accel, size_t accel_bytes, void *stream);
 size_t kk_closest_hit_accel_workspace_bytes(uint32_t ray_num);
-/* d_counters (optional, uint64[4], zeroed by the caller): 64-byte node records visited, triangles
- * tested, rays traced. */
+/* d_counters (optional, uint64[16], zeroed by the caller): [0] 128-byte node records visited,
+ * [1] triangles tested, [2] rays traced; diagnostics of the kernel's lane use: [3] passes of the wave
+ * loop, [4] lanes that visited a record in them, [5] triangle phases, [6] lanes in them, [7] visits
+ * that found no slot, [8] of those the ones that only the distance limit emptied. */
 int kk_closest_hit_accel(const void *d_accel, uint32_t face_num, uint32_t compacted_face_num,
                          const float *d_rays, uint32_t ray_num, float *d_t, float *d_bary,
                          uint32_t *d_prim, uint32_t flags, unsigned long long *d_counters,

@@ -38,8 +38,6 @@
 #include "kk_math.h"
 #include "traverse.h"
 
-#include <stdlib.h>
-
 namespace kk {
 namespace rsort {
 int sort_pairs(uint32_t *keysA, uint32_t *keysB, uint32_t *valsA, uint32_t *valsB, bool iota,
@@ -397,7 +395,7 @@ __device__ __forceinline__ uint32_t spread3(uint32_t v) { // 10 bits -> every th
 
 // key = Morton code of the origin inside the root box, KEY_BITS bits per axis (clamped); sorted with
 // KEY_PASSES 8-bit passes
-constexpr int KEY_BITS = 8;
+constexpr int KEY_BITS = 5;
 constexpr int KEY_PASSES = (3 * KEY_BITS + 7) / 8;
 __global__ __launch_bounds__(THREADS) void ray_keys_kernel(const Header *__restrict__ hdr,
                                                            const float *__restrict__ rays,
@@ -422,6 +420,9 @@ __global__ __launch_bounds__(THREADS) void ray_keys_kernel(const Header *__restr
 
 constexpr int STACK_DEPTH = 48; // <= 1 push per visited record, <= MAX_LEVELS records deep
 constexpr int LDS_DEPTH = 20;   // entries kept in LDS; deeper ones (rare) live in the workspace
+constexpr int REFILL_BELOW = 32;
+constexpr int PARK_MIN = 16; // run the triangle code once this many lanes wait for it ...
+constexpr int STEP_MIN = 24; // ... or fewer than this many lanes can still step
 constexpr uint32_t MAX_GRID = 1280; // 30 KB of LDS and < 96 VGPRs: five workgroups per CU
 // A product (b - o) * (1 / d) is within 3 * 2^-24 of the reference's fl((b - o) / d) (one rounding
 // each in 1 / d, the product, and the quotient it stands for); min / max keep the bound.
@@ -594,7 +595,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(5, 5)))
     const float *__restrict__ rays, const uint32_t *__restrict__ order, uint32_t rayNum,
     float *__restrict__ tOut, float *__restrict__ baryOut, uint32_t *__restrict__ primOut,
     uint32_t *rayCounter, const uint32_t *__restrict__ parents,
-    uint2 *__restrict__ spill, unsigned long long *counters, int PARK_MIN, int STEP_MIN, int REFILL_BELOW) {
+    uint2 *__restrict__ spill, unsigned long long *counters) {
     // groups waiting to be entered: childBase + (pending slots | internal-slot mask << 8)
     __shared__ uint32_t s_base[LDS_DEPTH * THREADS];
     __shared__ unsigned short s_bits[LDS_DEPTH * THREADS];
@@ -628,7 +629,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(5, 5)))
     Hit8 best;
     uint32_t nodeVisits = 0, triTests = 0;
     unsigned long long totNodes = 0, totTris = 0, totRays = 0;
-    unsigned long long dbgIters = 0, dbgVisitLanes = 0, dbgTriRuns = 0, dbgTriLanes = 0, dbgTriTrips = 0;
+    unsigned long long dbgIters = 0, dbgVisitLanes = 0, dbgTriRuns = 0, dbgTriLanes = 0, dbgEmpty = 0, dbgEmptyLimit = 0;
 
     auto restart = [&]() {
         best.t = FloatMax;
@@ -810,9 +811,9 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(5, 5)))
                 const uint32_t leafHits = hits & r1.z & 0xffu;
                 uint32_t inner = hits & imask;
                 if (COUNT && (leafHits | inner) == 0u) {
-                    ++dbgTriTrips; // visits that found nothing
+                    ++dbgEmpty; // visits that found nothing
                     if (anyNoLimit)
-                        dbgTriTrips += 1ull << 32; // ... because of the distance limit
+                        ++dbgEmptyLimit; // ... because of the distance limit
                 }
                 if (leafHits != 0u) {
                     // park the triangles from the first to the last leaf slot that was hit
@@ -885,10 +886,14 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(5, 5)))
             atomicAdd(&counters[5], dbgTriRuns);
             atomicAdd(&counters[6], dbgTriLanes);
         }
-        for (int o = 32; o > 0; o >>= 1)
-            dbgTriTrips += __shfl_xor(dbgTriTrips, o, 64);
-        if (lane == 0)
-            atomicAdd(&counters[7], dbgTriTrips);
+        for (int o = 32; o > 0; o >>= 1) {
+            dbgEmpty += __shfl_xor(dbgEmpty, o, 64);
+            dbgEmptyLimit += __shfl_xor(dbgEmptyLimit, o, 64);
+        }
+        if (lane == 0) {
+            atomicAdd(&counters[7], dbgEmpty);
+            atomicAdd(&counters[8], dbgEmptyLimit);
+        }
     }
 }
 
@@ -1010,13 +1015,10 @@ extern "C" int kk_closest_hit_accel(const void *d_accel, uint32_t face_num,
     uint2 *spill = reinterpret_cast<uint2 *>(b + w.spill);
     const auto *parents = reinterpret_cast<const uint32_t *>(ab + l.parents);
     const bool wt = (flags & KK_TRACE_WATERTIGHT) != 0;
-    int tune[3] = {16, 24, 40};
-    if (const char *e = getenv("KK_TUNE"))
-        sscanf(e, "%d,%d,%d", &tune[0], &tune[1], &tune[2]);
 #define KK_LAUNCH_TRACE(COUNT, WT)                                                                 \
     closest_hit_accel_kernel<COUNT, WT><<<grid, THREADS, 0, stream>>>(                              \
         hdr, wide, recs, d_rays, order, ray_num, d_t, d_bary, d_prim, rayCounter, parents, spill,  \
-        d_counters, tune[0], tune[1], tune[2])
+        d_counters)
     if (d_counters) {
         if (wt)
             KK_LAUNCH_TRACE(true, true);

@@ -36,7 +36,7 @@ def closest_hit(lbvh: LBVH, rays, count: bool = False, out=None, layout: str = "
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     else:
         t, bary, prim, ws = out
-    counters = torch.zeros(8, dtype=torch.int64, device=dev) if count else None
+    counters = torch.zeros(16, dtype=torch.int64, device=dev) if count else None
     with torch.cuda.device(dev):
         if layout == "trace":
             accel = lbvh.trace_accel()
@@ -59,7 +59,9 @@ def closest_hit(lbvh: LBVH, rays, count: bool = False, out=None, layout: str = "
     if count:
         c = counters.cpu().numpy()
         return t, bary, prim, {"node_fetches": int(c[0]), "tri_tests": int(c[1]), "rays": int(c[2]),
-                               "wave_stats": [int(x) for x in c[3:8]]}
+                               "wave_passes": int(c[3]), "visit_lanes": int(c[4]), "tri_phases": int(c[5]),
+                               "tri_lanes": int(c[6]), "empty_visits": int(c[7]),
+                               "empty_visits_by_limit": int(c[8])}
     return t, bary, prim
 
 

@@ -30,10 +30,12 @@ hdr = bvh.trace_accel()[:64].view(torch.int32).cpu().numpy()
 print("wide nodes:", int(hdr[10]), "of", int(hdr[7]), "binary nodes")
 got = closest_hit(bvh, rays, count=True)
 c = got[3]
-it, vl, tr, tl, tt = c["wave_stats"]
-print({k: round(v / R, 2) for k, v in c.items() if k != "wave_stats"})
-print(f"wave passes {it}, visit lanes/pass {vl / it:.1f}, tri phases {tr} ({tr / it:.3f}/pass), "
-      f"lanes/tri phase {tl / max(tr, 1):.1f}, empty visits/ray {(tt & 0xffffffff) / R:.2f}, of them by the limit {(tt >> 32) / R:.2f}")
+print({k: round(v / R, 2) for k, v in c.items()})
+it = max(c["wave_passes"], 1)
+print(f"visit lanes/pass {c['visit_lanes'] / it:.1f}, tri phases/pass {c['tri_phases'] / it:.3f}, "
+      f"lanes/tri phase {c['tri_lanes'] / max(c['tri_phases'], 1):.1f}")
 ms = timeit(lambda: closest_hit(bvh, rays))
 ms2 = timeit(lambda: closest_hit(bvh, rays, reuse_order=True))
 print(f"sorted: {ms:.3f} ms {R / ms / 1e3:.1f} Mrays/s; kernel only {ms2:.3f} ms {R / ms2 / 1e3:.1f} Mrays/s")
+ms3 = timeit(lambda: closest_hit(bvh, rays, sort=False))
+print(f"unsorted: {ms3:.3f} ms {R / ms3 / 1e3:.1f} Mrays/s")
