@@ -134,10 +134,22 @@ template <> struct MaxOf<uint16_t> {
     static constexpr float value = 65535.f;
 };
 
+// float(v) / max(T): for 8-bit voxels a 256-entry table in LDS holding exactly these quotients (an
+// IEEE division costs about ten instructions, eight of them per sample); 16-bit voxels divide.
+template <typename T> struct Norm;
+template <> struct Norm<uint8_t> {
+    const float *lut; // LDS, lut[v] = float(v) / 255.f
+    KK_D float operator()(uint8_t v) const { return lut[v]; }
+};
+template <> struct Norm<uint16_t> {
+    const float *lut; // unused
+    KK_D float operator()(uint16_t v) const { return static_cast<float>(v) / MaxOf<uint16_t>::value; }
+};
+
 // Trilinear sample of one brick. `sp` is the sample position in global atlas voxel coordinates,
 // `origin` the brick's first voxel in those coordinates.
 template <typename T>
-KK_D float sampleBrick(const T *__restrict__ brick, int A, i3 origin, f3 sp) {
+KK_D float sampleBrick(const T *__restrict__ brick, int A, i3 origin, f3 sp, const Norm<T> &norm) {
     const f3 b = sp - .5f;
     const f3 fl = vfloor(b);
     const float ax = b.x - fl.x, ay = b.y - fl.y, az = b.z - fl.z;
@@ -151,11 +163,10 @@ KK_D float sampleBrick(const T *__restrict__ brick, int A, i3 origin, f3 sp) {
     k = k < 0 ? 0 : (k > A - 2 ? A - 2 : k);
     const T *p = brick + (static_cast<size_t>(k) * A + j) * A + i;
     const int sy = A, sz = A * A;
-    constexpr float m = MaxOf<T>::value;
-    const float v000 = static_cast<float>(p[0]) / m, v001 = static_cast<float>(p[1]) / m;
-    const float v010 = static_cast<float>(p[sy]) / m, v011 = static_cast<float>(p[sy + 1]) / m;
-    const float v100 = static_cast<float>(p[sz]) / m, v101 = static_cast<float>(p[sz + 1]) / m;
-    const float v110 = static_cast<float>(p[sz + sy]) / m, v111 = static_cast<float>(p[sz + sy + 1]) / m;
+    const float v000 = norm(p[0]), v001 = norm(p[1]);
+    const float v010 = norm(p[sy]), v011 = norm(p[sy + 1]);
+    const float v100 = norm(p[sz]), v101 = norm(p[sz + 1]);
+    const float v110 = norm(p[sz + sy]), v111 = norm(p[sz + sy + 1]);
     const float c00 = (1.f - ax) * v000 + ax * v001;
     const float c01 = (1.f - ax) * v010 + ax * v011;
     const float c10 = (1.f - ax) * v100 + ax * v101;
@@ -165,32 +176,42 @@ KK_D float sampleBrick(const T *__restrict__ brick, int A, i3 origin, f3 sp) {
     return (1.f - az) * c0 + az * c1;
 }
 
-KK_D f4 tfLookup(const f4 *__restrict__ s_tf, float u) {
+// The table in LDS is padded: entry 0 and entries 257, 258 are zero, entry 1 + i is tf[i], so the two
+// taps of a lookup are read without range checks (the border colour of the texture is zero).
+constexpr int TF_LDS = 259;
+KK_D void tfStage(float4 *s_tf, const float *__restrict__ tf, int tid) { // 256 threads
+    s_tf[1 + tid] = reinterpret_cast<const float4 *>(tf)[tid];
+    if (tid < 3)
+        s_tf[tid == 0 ? 0 : 256 + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+KK_D f4 tfLookup(const float4 *__restrict__ s_tf, float u) {
     const float x = u * 256.f - .5f;
     const float fl = floorf(x);
     const float a = x - fl;
-    const int i = static_cast<int>(fl);
-    const f4 zero = {0.f, 0.f, 0.f, 0.f};
-    const f4 t0 = (i >= 0 && i <= 255) ? s_tf[i] : zero;
-    const f4 t1 = (i + 1 >= 0 && i + 1 <= 255) ? s_tf[i + 1] : zero;
-    return t0 * (1.f - a) + t1 * a;
+    int i = static_cast<int>(fl);
+    i = i < -1 ? -1 : (i > 256 ? 256 : i); // taps outside [0, 255] read zeros
+    const float4 t0 = s_tf[i + 1], t1 = s_tf[i + 2];
+    return f4{t0.x, t0.y, t0.z, t0.w} * (1.f - a) + f4{t1.x, t1.y, t1.z, t1.w} * a;
 }
 
 struct InLeaf {
     float tCurr, tExit;
 };
 
-template <typename T, bool COUNT>
+template <typename T, bool COUNT, bool SHADING>
 __global__ __launch_bounds__(THREADS) void dvr_kernel(const kk_vdb_device_data vdb,
                                                       const float *__restrict__ tf,
                                                       const kk_dvr_params rp, const kk_dvr_frame fr,
                                                       uint8_t *__restrict__ rgba, int W, int H, int y0,
                                                       int y1, int stripeFirst, int stripeStride,
                                                       unsigned long long *counters) {
-    __shared__ f4 s_tf[256];
+    __shared__ float4 s_tf[TF_LDS];
+    __shared__ float s_norm[256];
     const int tid = threadIdx.x;
-    s_tf[tid] = reinterpret_cast<const f4 *>(tf)[tid];
+    tfStage(s_tf, tf, tid);
+    s_norm[tid] = static_cast<float>(tid) / 255.f;
     __syncthreads();
+    const Norm<T> norm{s_norm};
 
     // 16 x 16 pixel block = 2 x 2 waves of 8 x 8 pixels
     const int lane = tid & 63, wave = tid >> 6;
@@ -355,27 +376,27 @@ __global__ __launch_bounds__(THREADS) void dvr_kernel(const kk_vdb_device_data v
                                        !(posInBrick.y >= dims0f) && !(posInBrick.z < 0.f) &&
                                        !(posInBrick.z >= dims0f)) {
                                     f3 samplePos = atlasBrickMinVoxPos + posInBrick;
-                                    const float scalar = sampleBrick<T>(brick, A, origin, samplePos);
+                                    const float scalar = sampleBrick<T>(brick, A, origin, samplePos, norm);
                                     const f4 tfCol = tfLookup(s_tf, scalar);
                                     f3 tfColRGB = {tfCol.x, tfCol.y, tfCol.z};
                                     if (COUNT)
                                         ++nSamples;
-                                    if (rp.use_shading) {
+                                    if (SHADING) {
                                         f3 N;
                                         samplePos.x += .5f;
-                                        float v0 = sampleBrick<T>(brick, A, origin, samplePos);
+                                        float v0 = sampleBrick<T>(brick, A, origin, samplePos, norm);
                                         samplePos.x -= 1.f;
-                                        float v1 = sampleBrick<T>(brick, A, origin, samplePos);
+                                        float v1 = sampleBrick<T>(brick, A, origin, samplePos, norm);
                                         N.x = v1 - v0;
                                         samplePos.y += .5f;
-                                        v0 = sampleBrick<T>(brick, A, origin, samplePos);
+                                        v0 = sampleBrick<T>(brick, A, origin, samplePos, norm);
                                         samplePos.y -= 1.f;
-                                        v1 = sampleBrick<T>(brick, A, origin, samplePos);
+                                        v1 = sampleBrick<T>(brick, A, origin, samplePos, norm);
                                         N.y = v1 - v0;
                                         samplePos.z += .5f;
-                                        v0 = sampleBrick<T>(brick, A, origin, samplePos);
+                                        v0 = sampleBrick<T>(brick, A, origin, samplePos, norm);
                                         samplePos.z -= 1.f;
-                                        v1 = sampleBrick<T>(brick, A, origin, samplePos);
+                                        v1 = sampleBrick<T>(brick, A, origin, samplePos, norm);
                                         N.z = v1 - v0;
                                         N = normalize(N);
                                         if (dot(eyeRay.dir, N) > 0.f)
@@ -490,9 +511,9 @@ __global__ __launch_bounds__(THREADS) void raw_kernel(const T *__restrict__ vol,
                                                       int target, uint8_t *__restrict__ rgba, int W,
                                                       int H, int y0, int y1,
                                                       unsigned long long *counters) {
-    __shared__ f4 s_tf[256];
+    __shared__ float4 s_tf[TF_LDS];
     const int tid = threadIdx.x;
-    s_tf[tid] = reinterpret_cast<const f4 *>(tf)[tid];
+    tfStage(s_tf, tf, tid);
     __syncthreads();
     const int lane = tid & 63, wave = tid >> 6;
     const int x = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
@@ -881,14 +902,24 @@ int launch(const kk_vdb_device_data *h_vdb, const float *d_tf, const kk_dvr_para
     if (y0 == y1 || stripeFirst >= stripes)
         return KK_OK;
     dim3 grid(div_up(width, 16), div_up(stripes - stripeFirst, stripeStride));
-    if (d_counters)
-        dvr_kernel<T, true><<<grid, THREADS, 0, stream>>>(*h_vdb, d_tf, *h_params, *h_frame, d_rgba,
-                                                          width, height, y0, y1, stripeFirst,
-                                                          stripeStride, d_counters);
-    else
-        dvr_kernel<T, false><<<grid, THREADS, 0, stream>>>(*h_vdb, d_tf, *h_params, *h_frame, d_rgba,
-                                                           width, height, y0, y1, stripeFirst,
-                                                           stripeStride, nullptr);
+    // the shading branch is a compile-time variant, like the reference's renderScene<T, ., UseShading>
+#define KK_LAUNCH_DVR(COUNT, SHADING)                                                              \
+    dvr_kernel<T, COUNT, SHADING><<<grid, THREADS, 0, stream>>>(*h_vdb, d_tf, *h_params, *h_frame, d_rgba, \
+                                                                width, height, y0, y1, stripeFirst,       \
+                                                                stripeStride, d_counters)
+    const bool shading = h_params->use_shading != 0;
+    if (d_counters) {
+        if (shading)
+            KK_LAUNCH_DVR(true, true);
+        else
+            KK_LAUNCH_DVR(true, false);
+    } else {
+        if (shading)
+            KK_LAUNCH_DVR(false, true);
+        else
+            KK_LAUNCH_DVR(false, false);
+    }
+#undef KK_LAUNCH_DVR
     KK_LAUNCH_CHECK();
     return KK_OK;
 }
