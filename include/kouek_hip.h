@@ -161,6 +161,17 @@ enum {
                                   reference's Moeller-Trumbore: hits may differ on grazing rays */
 };
 size_t kk_trace_accel_bytes(uint32_t face_num, uint32_t compacted_face_num);
+/* Where the pieces sit inside the accel buffer (byte offsets), for tools and tests that inspect it.
+ * header: 6 floats root box, uint32 face_num, uint32 binary node count, the nodes pointer, uint32
+ * wide node count (valid after the build). nodes: 128-byte records: float origin[3]; int8 exp[3];
+ * uint8 imask; uint32 childBase, triBase, leafMask (bit 8: counts do not fit a byte), triTotal;
+ * uint8 q[6][8] (minx maxx miny maxy minz maxz per slot); uint8 off[8], cnt[8]; 32 spare bytes.
+ * tris: 48-byte records: float v0[3]; uint32 face; float v1[3]; uint32 parent (binary node);
+ * float v2[3]; uint32 k (sorted position). parents: uint32 per binary node. */
+typedef struct kk_trace_accel_layout_info {
+    uint64_t header, nodes, tris, parents, total;
+} kk_trace_accel_layout_info;
+int kk_trace_accel_layout(uint32_t face_num, uint32_t compacted_face_num, kk_trace_accel_layout_info *out);
 /* d_accel: 256-byte aligned device buffer of kk_trace_accel_bytes(). */
 int kk_trace_accel_build(const kk_lbvh_device_data *d_lbvh, const float *d_positions,
                          const uint32_t *d_face_pos_idx, uint32_t face_num,

@@ -93,6 +93,7 @@ def _declare(l):
     l.kk_closest_hit.argtypes = [vp, vp, vp, vp, u32, vp, vp, vp, i32, vp, vp, sz, vp]
     l.kk_trace_accel_bytes.restype = sz
     l.kk_trace_accel_bytes.argtypes = [u32, u32]
+    l.kk_trace_accel_layout.argtypes = [u32, u32, vp]
     l.kk_trace_accel_build.argtypes = [vp, vp, vp, u32, u32, vp, sz, vp]
     l.kk_closest_hit_accel_workspace_bytes.restype = sz
     l.kk_closest_hit_accel_workspace_bytes.argtypes = [u32]

@@ -923,6 +923,18 @@ extern "C" size_t kk_trace_accel_bytes(uint32_t face_num, uint32_t compacted_fac
     return kk::accel::layout(face_num, compacted_face_num).total;
 }
 
+extern "C" int kk_trace_accel_layout(uint32_t face_num, uint32_t compacted_face_num,
+                                     kk_trace_accel_layout_info *out) {
+    KK_REQUIRE(out != nullptr, "null pointer");
+    const kk::accel::Layout l = kk::accel::layout(face_num, compacted_face_num);
+    out->header = l.header;
+    out->nodes = l.nodes;
+    out->tris = l.tris;
+    out->parents = l.parents;
+    out->total = l.total;
+    return KK_OK;
+}
+
 extern "C" int kk_trace_accel_build(const kk_lbvh_device_data *d_lbvh, const float *d_positions,
                                     const uint32_t *d_face_pos_idx, uint32_t face_num,
                                     uint32_t compacted_face_num, void *d_accel, size_t accel_bytes,
