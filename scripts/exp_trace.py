@@ -1,5 +1,5 @@
-"""Times the closest-hit variants against each other on the benchmark workload and checks that they agree."""
-import sys, os, time
+"""Closest hit on the benchmark workload: time, work counters and per-wave utilisation figures."""
+import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from raytracer_amd import synthetic as syn
@@ -14,26 +14,28 @@ bvh = LBVH(dev)
 bvh.BuildFrom(torch.from_numpy(pos), torch.from_numpy(tri.view(np.int32)))
 rays = torch.from_numpy(syn.incoherent_rays(R)).to(dev)
 
-def timeit(fn, n=5):
+
+def timeit(fn, n=10):
     fn(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(n): fn()
+    for _ in range(n):
+        fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n
 
-ref = closest_hit(bvh, rays, layout="build", count=True)
-print("build-layout: %.3f ms" % timeit(lambda: closest_hit(bvh, rays, layout="build")), ref[3], flush=True)
-print("accel build: %.3f ms" % timeit(lambda: bvh.trace_accel(rebuild=True)), flush=True)
-for sort in (False, True):
-    got = closest_hit(bvh, rays, layout="trace", sort=sort, count=True)
-    ms = timeit(lambda: closest_hit(bvh, rays, layout="trace", sort=sort))
-    same_p = bool((got[2] == ref[2]).all()); same_t = bool((got[0] == ref[0]).all()); same_b = bool((got[1] == ref[1]).all())
-    print(f"trace-layout sort={sort}: {ms:.3f} ms  {R/ms/1e3:.1f} Mrays/s  prim_eq={same_p} t_eq={same_t} bary_eq={same_b}",
-          {k: (round(v / R, 2) if k != 'dbg' else v) for k, v in got[3].items()}, flush=True)
-from raytracer_amd import _lib
-l = _lib.lib()
-ws = torch.zeros(l.kk_closest_hit_accel_workspace_bytes(R), dtype=torch.uint8, device=dev)
-t = torch.empty(R, dtype=torch.float32, device=dev); b = torch.empty((R, 2), dtype=torch.float32, device=dev); pr = torch.empty(R, dtype=torch.int32, device=dev)
-closest_hit(bvh, rays, out=(t, b, pr, ws)); torch.cuda.synchronize()
-print("exact-list length:", int(ws[:256].view(torch.int32)[16]), "queue heads:", ws[:256].view(torch.int32)[[0, 32]].tolist())
+
+print("accel build: %.3f ms" % timeit(lambda: bvh.trace_accel(rebuild=True), 3), flush=True)
+hdr = bvh.trace_accel()[:64].view(torch.int32).cpu().numpy()
+print("wide nodes:", int(hdr[10]), "of", int(hdr[7]), "binary nodes")
+got = closest_hit(bvh, rays, count=True)
+c = got[3]
+print({k: round(v / R, 2) for k, v in c.items()})
+it = max(c["wave_passes"], 1)
+print(f"visit lanes/pass {c['visit_lanes'] / it:.1f}, tri phases/pass {c['tri_phases'] / it:.3f}, "
+      f"lanes/tri phase {c['tri_lanes'] / max(c['tri_phases'], 1):.1f}")
+ms = timeit(lambda: closest_hit(bvh, rays))
+ms2 = timeit(lambda: closest_hit(bvh, rays, reuse_order=True))
+print(f"sorted: {ms:.3f} ms {R / ms / 1e3:.1f} Mrays/s; kernel only {ms2:.3f} ms {R / ms2 / 1e3:.1f} Mrays/s")
+ms3 = timeit(lambda: closest_hit(bvh, rays, sort=False))
+print(f"unsorted: {ms3:.3f} ms {R / ms3 / 1e3:.1f} Mrays/s")
