@@ -433,6 +433,12 @@ __device__ __forceinline__ float4 ld4(const char *p) { return *reinterpret_cast<
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
+constexpr uint32_t QUEUES = 8;        // XCDs of the device
+constexpr uint32_t QUEUE_STRIDE = 32; // counters 128 bytes apart
+
+// which XCD this wave runs on (hardware register XCC_ID, bits 3:0)
+__device__ __forceinline__ uint32_t xcc_id() { return __builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xfu; }
+
 struct RayState {
     f3 pos, dir, inv;
 };
@@ -613,6 +619,12 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(5, 5)))
     rootBox.minPos = {hdr->rootBox[0], hdr->rootBox[1], hdr->rootBox[2]};
     rootBox.maxPos = {hdr->rootBox[3], hdr->rootBox[4], hdr->rootBox[5]};
 
+    // Rays are handed out from one queue per XCD (consecutive eighths of the sorted order, i.e. of
+    // space): the workgroups of an XCD share its L2, so they should walk the same part of the tree.
+    // A wave whose queue is used up moves on to the next one.
+    const uint32_t queueLen = (rayNum + QUEUES - 1) / QUEUES;
+    uint32_t queue = xcc_id() % QUEUES, queuesTried = 0;
+
     bool active = false;   // walking, or holding parked triangles
     bool finished = false; // walk over, result not yet written
     bool poolEmpty = false;
@@ -670,15 +682,20 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(5, 5)))
         if (idleMask != 0ull && !poolEmpty) {
             const uint32_t want = __popcll(idleMask);
             const int leader = __ffsll(static_cast<long long>(idleMask)) - 1;
+            const uint32_t qBegin = queue * queueLen;
+            const uint32_t qLen = qBegin >= rayNum ? 0u : (rayNum - qBegin < queueLen ? rayNum - qBegin : queueLen);
             uint32_t base = 0;
             if (lane == leader)
-                base = atomicAdd(rayCounter, want);
+                base = atomicAdd(rayCounter + queue * QUEUE_STRIDE, want);
             base = __shfl(base, leader, 64);
-            if (base + want >= rayNum || base + want < base)
-                poolEmpty = true;
+            if (base + want >= qLen || base + want < base) { // used up: the next refill asks the next queue
+                queue = queue + 1 == QUEUES ? 0u : queue + 1;
+                poolEmpty = ++queuesTried == QUEUES;
+            }
             if (!active) {
-                const uint32_t r = base + __popcll(idleMask & lanesBelow);
-                if (r < rayNum && r >= base) {
+                const uint32_t rel = base + __popcll(idleMask & lanesBelow);
+                if (rel < qLen && rel >= base) {
+                    const uint32_t r = qBegin + rel;
                     rayIdx = order ? order[r] : r;
                     const float *p = rays + 6ull * rayIdx;
                     ray.pos = {p[0], p[1], p[2]};
@@ -714,8 +731,8 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(5, 5)))
             }
         }
         if (__ballot(active) == 0ull) {
-            if (__ballot(finished) != 0ull)
-                continue; // only retirements left
+            if (__ballot(finished) != 0ull || !poolEmpty)
+                continue; // retirements left, or another queue to ask
             break;
         }
 
@@ -904,7 +921,7 @@ inline TraceWs trace_ws(uint32_t rayNum) {
     TraceWs w;
     Carver c;
     const size_t n = rayNum ? rayNum : 1;
-    w.counter = c.take(256); // [0] ray queue head
+    w.counter = c.take(4 * QUEUES * QUEUE_STRIDE); // ray queue heads
     w.spill = c.take(sizeof(uint2) * MAX_GRID * THREADS * (STACK_DEPTH - LDS_DEPTH));
     w.keysA = c.take(4 * n);
     w.keysB = c.take(4 * n);
@@ -1004,7 +1021,7 @@ extern "C" int kk_closest_hit_accel(const void *d_accel, uint32_t face_num,
     const auto *recs = reinterpret_cast<const TriRec *>(ab + l.tris);
     char *b = static_cast<char *>(d_workspace);
     uint32_t *rayCounter = reinterpret_cast<uint32_t *>(b + w.counter);
-    KK_HIP_TRY(hipMemsetAsync(rayCounter, 0, 256, stream));
+    KK_HIP_TRY(hipMemsetAsync(rayCounter, 0, 4 * QUEUES * QUEUE_STRIDE, stream));
 
     const uint32_t *order = nullptr;
     if (flags & KK_TRACE_REUSE_ORDER) {
