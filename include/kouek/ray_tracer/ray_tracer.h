@@ -50,6 +50,7 @@ class RayTracer : Noncopyable {
     HIP::DeviceBuffer<Light> d_lights;
     HIP::DeviceBuffer<Material> d_materials;
     HIP::DeviceBuffer<vec3> d_accuRndrTo;
+    HIP::DeviceBuffer<uint8_t> d_traceTree; // the 8-wide tree the path tracer walks
 
     static constexpr std::string_view ErrTag = "[RayTracer Error]";
     static constexpr uint32_t Seed = 1234; // curand_init(1234, pixel, 0) in the reference
@@ -115,7 +116,28 @@ class RayTracer : Noncopyable {
         scene.light_tot_area = tot;
         modified = true;
     }
-    void SetLBVH(std::shared_ptr<LBVH> lbvh) { this->lbvh = lbvh; }
+    // Also builds the trace-side tree of `lbvh` (kk_trace_accel_build); the image is the same with
+    // and without it, it only makes the hits cheaper to find.
+    void SetLBVH(std::shared_ptr<LBVH> lbvh) {
+        this->lbvh = lbvh;
+        scene.trace_accel = nullptr;
+        if (!lbvh || !lbvh->IsComplete())
+            return;
+        const auto &dd = lbvh->GetDeviceData();
+        const size_t bytes = kk_trace_accel_bytes(dd.faceNum, dd.compactedFaceNum);
+        if (!d_traceTree.resize(bytes))
+            return;
+        if (!KOUEK_HIP_CHECK(ErrTag.data(),
+                             kk_trace_accel_build(reinterpret_cast<const kk_lbvh_device_data *>(
+                                                      lbvh->GetDeivceDataDevicePtr()),
+                                                  lbvh->GetDevicePositions(),
+                                                  lbvh->GetDeviceFacePositionIndices(), dd.faceNum,
+                                                  dd.compactedFaceNum, d_traceTree.data(), bytes, nullptr)))
+            return;
+        scene.trace_accel = d_traceTree.data();
+        scene.accel_face_num = dd.faceNum;
+        scene.accel_compacted_face_num = dd.compactedFaceNum;
+    }
     void SetWorldToScene(const mat4 &w2s) { setFloats(scene.w2s, &w2s[0][0], 16); }
     void SetCameraToWorld(const vec3 &eyePos2w, const mat3 &eyeRot2w) {
         setFloats(frame.eye_pos, &eyePos2w[0], 3);

@@ -244,6 +244,11 @@ typedef struct kk_pt_scene {
     const kk_material *materials;
     float light_tot_area;
     uint32_t _pad2;
+    /* Optional: the trace-side tree of the same LBVH (kk_trace_accel_build) and the sizes it was
+     * built with. When set, closest hits and shadow rays of kk_pt_render_sample walk it instead of
+     * the binary tree; the image is the same. */
+    const void *trace_accel;
+    uint32_t accel_face_num, accel_compacted_face_num;
 } kk_pt_scene;
 
 /* RayTracer::RenderParameterPerFrame (ray_tracer.h:50-53); eye_rot column-major mat3 */

@@ -3,14 +3,17 @@
 //   ray generation (:592-619), renderScene (:312-431) with Material::BRDF and the light sampling of
 //   include/ray_tracer/material.h:41-48,100-114 and the helpers of include/cg/math.h:75-129,
 //   running-mean accumulation and RGBA8 output (:623-637).
-// Closest hits use the walk of traverse.h. Shadow rays only need "is anything nearer than the light"
-// (:381-383 compares the closest t with the distance), so they stop at the first such triangle.
+// Closest hits use the walk of traverse.h over the build's own arrays or, when the scene names a
+// trace-side tree, the 8-wide walk of wide_walk.h (same hits). Shadow rays only need "is anything
+// nearer than the light" (:381-383 compares the closest t with the distance), so they stop at the
+// first such triangle.
 // Random numbers: the reference draws from cuRAND XORWOW, curand_init(1234, pixel, 0); cuRAND does not
 // exist on this platform, so a counter-based Philox4x32-10 keyed by (seed; draw, sample, pixel) is used,
 // drawn in the reference's order, which also makes a pixel's stream independent of how the image is
 // split between GPUs.
 #include "kk_host.h"
 #include "traverse.h"
+#include "wide_walk.h"
 
 namespace kk {
 namespace pt {
@@ -161,17 +164,42 @@ KK_D bool occluded(const trav::Scene &s, const Ray &ray, float tMax, uint32_t *s
     }
 }
 
+// The two ways a lane finds hits: the binary tree as built, or the 8-wide trace-side tree.
+struct BinaryTracer {
+    trav::Scene s;
+    uint32_t *stack;
+    int stride;
+    KK_D void closest(const Ray &ray, float &t, float &bx, float &by, uint32_t &fi) const {
+        uint32_t a = 0, b = 0;
+        const trav::Hit h = trav::closest_hit<false>(s, ray, stack, stride, a, b);
+        t = h.t, bx = h.bx, by = h.by, fi = h.fi;
+    }
+    KK_D bool shadowed(const Ray &ray, float tMax) const { return occluded(s, ray, tMax, stack, stride); }
+};
+struct WideTracer {
+    accel::View v;
+    accel::LaneStack st;
+    KK_D void closest(const Ray &ray, float &t, float &bx, float &by, uint32_t &fi) const {
+        const accel::Hit8 h = accel::closest_hit_lane(v, ray, st);
+        t = h.t, bx = h.bx, by = h.by, fi = h.fi;
+    }
+    KK_D bool shadowed(const Ray &ray, float tMax) const { return accel::occluded_lane(v, ray, tMax, st); }
+};
+
 // src/ray_tracer/ray_tracer_render.cu:312-431
-KK_D f3 renderScene(const trav::Scene &s, const kk_pt_scene &p, Rng &rng, Ray ray, uint32_t *stack,
-                    int stride) {
+template <typename Tracer>
+KK_D f3 renderScene(const Tracer &tracer, const kk_pt_scene &p, Rng &rng, Ray ray) {
     constexpr float RR = .8f;
     f3 throughout = F3(1.f);
     f3 Lo = F3(0.f);
-    uint32_t dummyA = 0, dummyB = 0;
     for (uint8_t depth = 0;
          depth < p.max_path_depth && gmax(throughout.x, gmax(throughout.y, throughout.z)) >= FloatEps;
          ++depth) {
-        const trav::Hit nearest = trav::closest_hit<false>(s, ray, stack, stride, dummyA, dummyB);
+        struct {
+            float t, bx, by;
+            uint32_t fi;
+        } nearest;
+        tracer.closest(ray, nearest.t, nearest.bx, nearest.by, nearest.fi);
         if (nearest.t == FloatMax)
             break;
         const kk_pt_triangle triangle = p.triangles[nearest.fi];
@@ -201,7 +229,7 @@ KK_D f3 renderScene(const trav::Scene &s, const kk_pt_scene &p, Rng &rng, Ray ra
                                  sqrIn * lht.area / p.light_tot_area;
             if (factor < FloatEps)
                 continue;
-            if (occluded(s, ray, sqrtf(sqrIn) - Eps, stack, stride))
+            if (tracer.shadowed(ray, sqrtf(sqrIn) - Eps))
                 continue;
             Li = Li + factor / ls.pdf * V(lht.radiance) * BRDF(matr, ray.dir, dirOut, norm);
         }
@@ -238,25 +266,21 @@ KK_D f3 renderScene(const trav::Scene &s, const kk_pt_scene &p, Rng &rng, Ray ra
     return Lo;
 }
 
+template <bool WIDE>
 __global__ __launch_bounds__(THREADS) void path_trace_kernel(
-    const kk_lbvh_device_data *__restrict__ lbvh, const kk_pt_scene p, const kk_pt_frame f,
-    float *__restrict__ accum, uint8_t *__restrict__ rgba, int W, int H, int y0, int y1,
+    const kk_lbvh_device_data *__restrict__ lbvh, const accel::View view, const kk_pt_scene p,
+    const kk_pt_frame f, float *__restrict__ accum, uint8_t *__restrict__ rgba, int W, int H, int y0, int y1,
     float sampleIdx, uint32_t seed) {
-    __shared__ uint32_t s_stack[trav::STACK_DEPTH * THREADS];
+    // binary walk: one word per entry; wide walk: a group (base word + 16 bits) per entry
+    constexpr int WORDS = WIDE ? accel::LANE_LDS_DEPTH : trav::STACK_DEPTH;
+    __shared__ uint32_t s_stack[WORDS * THREADS];
+    __shared__ unsigned short s_bits[WIDE ? accel::LANE_LDS_DEPTH * THREADS : 1];
     const int tid = threadIdx.x;
     // a wave covers a 16 x 4 pixel patch of the tile
     const int x = blockIdx.x * TILE_W + (tid & (TILE_W - 1));
     const int y = y0 + blockIdx.y * TILE_H + (tid / TILE_W);
     if (x >= W || y >= y1)
         return;
-    trav::Scene s;
-    s.nodes = lbvh->internal_nodes;
-    s.faces = lbvh->faces;
-    s.compacted = lbvh->compacted_faces;
-    s.faceNum = lbvh->face_num;
-    s.compactedNum = lbvh->compacted_face_num;
-    s.positions = p.positions;
-    s.tri = p.tri_to_position_indices;
 
     const uint32_t idx = static_cast<uint32_t>(y) * W + x;
     Rng rng{seed, idx, static_cast<uint32_t>(sampleIdx), 0};
@@ -288,7 +312,23 @@ __global__ __launch_bounds__(THREADS) void path_trace_kernel(
         const f4 pp = w2s * f4{f.eye_pos[0], f.eye_pos[1], f.eye_pos[2], 1.f};
         eyeRay.pos = {pp.x, pp.y, pp.z};
     }
-    f3 color = renderScene(s, p, rng, eyeRay, s_stack + tid, THREADS);
+    f3 color;
+    if (WIDE) {
+        const WideTracer tracer{view, accel::LaneStack{s_stack + tid, s_bits + tid, THREADS}};
+        color = renderScene(tracer, p, rng, eyeRay);
+    } else {
+        BinaryTracer tracer;
+        tracer.s.nodes = lbvh->internal_nodes;
+        tracer.s.faces = lbvh->faces;
+        tracer.s.compacted = lbvh->compacted_faces;
+        tracer.s.faceNum = lbvh->face_num;
+        tracer.s.compactedNum = lbvh->compacted_face_num;
+        tracer.s.positions = p.positions;
+        tracer.s.tri = p.tri_to_position_indices;
+        tracer.stack = s_stack + tid;
+        tracer.stride = THREADS;
+        color = renderScene(tracer, p, rng, eyeRay);
+    }
     const f3 prev = {accum[3ull * idx], accum[3ull * idx + 1], accum[3ull * idx + 2]};
     color = prev + (color - prev) / sampleIdx;
     accum[3ull * idx] = color.x;
@@ -330,8 +370,18 @@ extern "C" int kk_pt_render_sample(const kk_lbvh_device_data *d_lbvh, const kk_p
     if (y0 == y1)
         return KK_OK;
     dim3 grid(div_up(width, TILE_W), div_up(y1 - y0, TILE_H));
-    path_trace_kernel<<<grid, THREADS, 0, static_cast<hipStream_t>(stream_)>>>(
-        d_lbvh, *h_scene, *h_frame, d_accum, d_rgba, width, height, y0, y1, sample_index, seed);
+    if (h_scene->trace_accel) {
+        KK_REQUIRE(h_scene->accel_face_num > 0 && h_scene->accel_compacted_face_num > 0 &&
+                       h_scene->accel_compacted_face_num <= h_scene->accel_face_num,
+                   "trace accel sizes out of range");
+        const accel::View view =
+            accel::make_view(h_scene->trace_accel, h_scene->accel_face_num, h_scene->accel_compacted_face_num);
+        path_trace_kernel<true><<<grid, THREADS, 0, static_cast<hipStream_t>(stream_)>>>(
+            d_lbvh, view, *h_scene, *h_frame, d_accum, d_rgba, width, height, y0, y1, sample_index, seed);
+    } else
+        path_trace_kernel<false><<<grid, THREADS, 0, static_cast<hipStream_t>(stream_)>>>(
+            d_lbvh, accel::View{}, *h_scene, *h_frame, d_accum, d_rgba, width, height, y0, y1, sample_index,
+            seed);
     KK_LAUNCH_CHECK();
     return KK_OK;
 }

@@ -37,6 +37,7 @@
 #include "kk_host.h"
 #include "kk_math.h"
 #include "traverse.h"
+#include "wide_walk.h"
 
 namespace kk {
 namespace rsort {
@@ -48,45 +49,8 @@ extern "C" size_t kk_sort_workspace_bytes(uint32_t n);
 
 namespace accel {
 
-using trav::LEAF;
-using trav::LEAF_MASK;
-
 constexpr int THREADS = 256;
 constexpr float LEAF_PAD = 1e-5f; // leaf boxes grow by this fraction of the scene's largest coordinate
-constexpr uint32_t EMPTY = 0xFFFFFFFFu;
-
-struct alignas(128) Wide8 {
-    float origin[3];
-    int8_t exp[3];
-    uint8_t imask;      // slots that hold a binary subtree
-    uint32_t childBase; // wide node of the first such slot; the others follow in slot order
-    uint32_t triBase;   // first TriRec of this node's leaf slots
-    uint32_t leafMask;  // bits 0-7: slots that hold a leaf; LONG_RUN: off / cnt do not fit a byte
-    uint32_t triTotal;  // triangles of all leaf slots
-    uint8_t q[6][8];    // minx[8] maxx[8] miny[8] maxy[8] minz[8] maxz[8]
-    uint8_t off[8];     // first triangle of a leaf slot, relative to triBase
-    uint8_t cnt[8];     // its triangle count
-    uint32_t spare[8];
-};
-static_assert(sizeof(Wide8) == 128, "one cache line");
-constexpr uint32_t LONG_RUN = 0x100u;
-
-struct alignas(16) TriRec {
-    float v0[3];
-    uint32_t fi;
-    float v1[3];
-    uint32_t parent; // binary node whose child is this triangle's leaf
-    float v2[3];
-    uint32_t k; // position in the build's sorted face order
-};
-static_assert(sizeof(TriRec) == 48, "three 16-byte loads");
-
-struct alignas(256) Header {
-    float rootBox[6];
-    uint32_t faceNum, nodeNum;
-    const kk_lbvh_node *nodes; // the build's own nodes (parent boxes for the acceptance test)
-    uint32_t wideNum;
-};
 
 // A binary path fixes one more Morton bit per level, a wide level descends at least one binary level.
 constexpr int MAX_LEVELS = 32;
@@ -424,163 +388,11 @@ constexpr int REFILL_BELOW = 32;
 constexpr int PARK_MIN = 16; // run the triangle code once this many lanes wait for it ...
 constexpr int STEP_MIN = 24; // ... or fewer than this many lanes can still step
 constexpr uint32_t MAX_GRID = 1280; // 30 KB of LDS and < 96 VGPRs: five workgroups per CU
-// A product (b - o) * (1 / d) is within 3 * 2^-24 of the reference's fl((b - o) / d) (one rounding
-// each in 1 / d, the product, and the quotient it stands for); min / max keep the bound.
-constexpr float SLAB_REL = 1e-6f, SLAB_ABS = 1e-30f;
-constexpr float SLAB_SHRINK = 1.f - 1e-6f; // the same margin as a factor on the entry distance
-
 __device__ __forceinline__ float4 ld4(const char *p) { return *reinterpret_cast<const float4 *>(p); }
-
-typedef float v2f __attribute__((ext_vector_type(2)));
-
 constexpr uint32_t QUEUES = 8;        // XCDs of the device
 constexpr uint32_t QUEUE_STRIDE = 32; // counters 128 bytes apart
-
 // which XCD this wave runs on (hardware register XCC_ID, bits 3:0)
 __device__ __forceinline__ uint32_t xcc_id() { return __builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xfu; }
-
-struct RayState {
-    f3 pos, dir, inv;
-};
-
-// Does `r` pass the slab test of the build's node `parent`, as the reference computes it?
-__device__ __forceinline__ bool passes_parent(const kk_lbvh_node *__restrict__ nodes, uint32_t parent,
-                                              const RayState &r) {
-    const trav::NodeData nd = trav::load_node(nodes, parent);
-    const float h0 = (nd.box.minPos.x - r.pos.x) * r.inv.x, h1 = (nd.box.maxPos.x - r.pos.x) * r.inv.x;
-    const float h2 = (nd.box.minPos.y - r.pos.y) * r.inv.y, h3 = (nd.box.maxPos.y - r.pos.y) * r.inv.y;
-    const float h4 = (nd.box.minPos.z - r.pos.z) * r.inv.z, h5 = (nd.box.maxPos.z - r.pos.z) * r.inv.z;
-    float en = fmaxf(fmaxf(fminf(h0, h1), fminf(h2, h3)), fminf(h4, h5));
-    const float ex = fminf(fminf(fmaxf(h0, h1), fmaxf(h2, h3)), fmaxf(h4, h5));
-    en = fmaxf(en, 0.f);
-    const float m = SLAB_REL * fmaxf(en, fabsf(ex)) + SLAB_ABS;
-    if (en <= ex - m)
-        return true;
-    if (en > ex + m)
-        return false;
-    Ray ray{r.pos, r.dir};
-    float tEnter, tExit;
-    HitAABB(ray, nd.box, tEnter, tExit);
-    return !(tEnter > tExit);
-}
-
-// Does `r` pass the reference's slab test of node `p` and of every node above it?
-__device__ __forceinline__ bool passes_chain(const kk_lbvh_node *__restrict__ nodes,
-                                             const uint32_t *__restrict__ parents, uint32_t p,
-                                             const RayState &r) {
-    const Ray ray{r.pos, r.dir};
-    while (p != EMPTY) {
-        const trav::NodeData nd = trav::load_node(nodes, p);
-        float tEnter, tExit;
-        HitAABB(ray, nd.box, tEnter, tExit);
-        if (tEnter > tExit)
-            return false;
-        p = parents[p];
-    }
-    return true;
-}
-
-enum : uint32_t { MODE_FAST = 0, MODE_CAREFUL = 1, MODE_CHAIN = 2 };
-
-// Triangles [k0, k0 + n) against the ray. Normally a better hit is taken at once and whether its
-// leaf's parent box passes the reference's slab test is checked once, for the final hit, when the ray
-// retires (MODE_FAST). A ray being re-traced after that check failed checks every hit it takes
-// (MODE_CAREFUL); a ray with a zero direction component checks the whole chain of boxes (MODE_CHAIN).
-//
-// WATERTIGHT replaces the reference's Moeller-Trumbore test by the shear-and-scale test of Woop,
-// Benthin and Wald (2013), two-sided, with its double-precision fallback on an edge: a ray through a
-// shared edge or vertex cannot slip between two triangles. It is an option, not the default, because
-// its hit / miss decisions differ from the reference's on grazing rays.
-struct Shear {
-    int kx, ky, kz;
-    float sx, sy, sz;
-};
-__device__ __forceinline__ Shear make_shear(f3 d) {
-    Shear s;
-    const float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
-    s.kz = (ax > ay) ? (ax > az ? 0 : 2) : (ay > az ? 1 : 2);
-    s.kx = s.kz + 1 == 3 ? 0 : s.kz + 1;
-    s.ky = s.kx + 1 == 3 ? 0 : s.kx + 1;
-    if (d[s.kz] < 0.f) {
-        const int t = s.kx;
-        s.kx = s.ky;
-        s.ky = t;
-    }
-    s.sx = d[s.kx] / d[s.kz];
-    s.sy = d[s.ky] / d[s.kz];
-    s.sz = 1.f / d[s.kz];
-    return s;
-}
-// returns t (< 0: miss); bx, by = weights of v1 and v2 like the reference's barycentrics
-__device__ __forceinline__ float hit_watertight(const Shear &s, f3 org, f3 v0, f3 v1, f3 v2, float &bx,
-                                                float &by) {
-    const f3 A = v0 - org, B = v1 - org, C = v2 - org;
-    const float Ax = A[s.kx] - s.sx * A[s.kz], Ay = A[s.ky] - s.sy * A[s.kz];
-    const float Bx = B[s.kx] - s.sx * B[s.kz], By = B[s.ky] - s.sy * B[s.kz];
-    const float Cx = C[s.kx] - s.sx * C[s.kz], Cy = C[s.ky] - s.sy * C[s.kz];
-    float U = Cx * By - Cy * Bx, V = Ax * Cy - Ay * Cx, W = Bx * Ay - By * Ax;
-    if (U == 0.f || V == 0.f || W == 0.f) {
-        U = static_cast<float>(static_cast<double>(Cx) * By - static_cast<double>(Cy) * Bx);
-        V = static_cast<float>(static_cast<double>(Ax) * Cy - static_cast<double>(Ay) * Cx);
-        W = static_cast<float>(static_cast<double>(Bx) * Ay - static_cast<double>(By) * Ax);
-    }
-    if ((U < 0.f || V < 0.f || W < 0.f) && (U > 0.f || V > 0.f || W > 0.f))
-        return -1.f;
-    const float det = U + V + W;
-    if (det == 0.f)
-        return -1.f;
-    const float Az = s.sz * A[s.kz], Bz = s.sz * B[s.kz], Cz = s.sz * C[s.kz];
-    const float T = U * Az + V * Bz + W * Cz;
-    const float inv = 1.f / det;
-    const float t = T * inv;
-    if (!(t >= 0.f))
-        return -1.f;
-    bx = V * inv;
-    by = W * inv;
-    return t;
-}
-
-struct Hit8 {
-    float t, bx, by;
-    uint32_t fi; // face index, 0xFFFFFFFF = miss
-    uint32_t k;  // position in the sorted face order: the smaller one wins among equal t
-    uint32_t w;  // its TriRec
-};
-
-template <bool COUNT, bool WATERTIGHT>
-__device__ __forceinline__ void test_run(const TriRec *__restrict__ recs,
-                                         const kk_lbvh_node *__restrict__ nodes,
-                                         const uint32_t *__restrict__ parents, const RayState &r,
-                                         uint32_t mode, uint32_t w0, uint32_t n, Hit8 &best,
-                                         uint32_t &triTests) {
-    const Ray ray{r.pos, r.dir};
-    Shear shear{};
-    if (WATERTIGHT && n != 0u)
-        shear = make_shear(r.dir);
-    for (uint32_t w = w0; w < w0 + n; ++w) {
-        const uint4 *p = reinterpret_cast<const uint4 *>(recs + w);
-        const uint4 a = p[0], b = p[1], c = p[2];
-        float bx = 0.f, by = 0.f;
-        const f3 v0 = F3(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z));
-        const f3 v1 = F3(__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z));
-        const f3 v2 = F3(__uint_as_float(c.x), __uint_as_float(c.y), __uint_as_float(c.z));
-        const float t = WATERTIGHT ? hit_watertight(shear, r.pos, v0, v1, v2, bx, by)
-                                   : HitTriangle(ray, v0, v1, v2, bx, by);
-        if (COUNT)
-            ++triTests;
-        if (t >= 0.f && (t < best.t || (t == best.t && c.w < best.k))) {
-            if (mode == MODE_FAST || (mode == MODE_CAREFUL ? passes_parent(nodes, b.w, r)
-                                                           : passes_chain(nodes, parents, b.w, r))) {
-                best.t = t;
-                best.bx = bx;
-                best.by = by;
-                best.fi = a.w;
-                best.k = c.w;
-                best.w = w;
-            }
-        }
-    }
-}
 
 // Persistent wave64 workgroups pull rays (in sorted order) from a global counter. Per iteration every
 // lane is at the same place in the code: (A) lanes without a node take the next child of their current
@@ -630,8 +442,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(5, 5)))
     bool poolEmpty = false;
     uint32_t rayIdx = 0;
     RayState ray;
-    bool negX = false, negY = false, negZ = false; // which of min / max is the near plane
-    uint32_t oct = 0;                              // negX | negY << 1 | negZ << 2
+    RaySigns sg{false, false, false, 0u};          // which of min / max is the near plane; octant
     uint32_t cur = 0;                              // node to visit next
     bool have = false;                             // cur is valid
     uint32_t grpBase = 0, grpBits = 0;             // current group (see above)
@@ -651,7 +462,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(5, 5)))
         pendC = 0u;
         // a group that holds just the root: slot 0 of a node whose only internal slot is slot 0
         grpBase = 0u;
-        grpBits = (1u << (0u ^ oct)) | (1u << 8);
+        grpBits = (1u << (0u ^ sg.oct)) | (1u << 8);
         have = false;
         active = true;
     };
@@ -698,27 +509,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(5, 5)))
                     const uint32_t r = qBegin + rel;
                     rayIdx = order ? order[r] : r;
                     const float *p = rays + 6ull * rayIdx;
-                    ray.pos = {p[0], p[1], p[2]};
-                    ray.dir = {p[3], p[4], p[5]};
-                    ray.inv = 1.f / ray.dir;
-                    const bool regular = fabsf(ray.inv.x) < 1e18f && fabsf(ray.inv.y) < 1e18f &&
-                                         fabsf(ray.inv.z) < 1e18f; // false for 0, denormal, NaN
-                    mode = MODE_FAST;
-                    if (!regular) {
-                        // finite stand-ins keep the walk a superset of the reference's visits:
-                        // inside a slab -> (-huge, +huge), outside -> both the same sign
-                        mode = MODE_CHAIN;
-                        if (!(fabsf(ray.inv.x) < 1e18f))
-                            ray.inv.x = copysignf(1e18f, ray.dir.x);
-                        if (!(fabsf(ray.inv.y) < 1e18f))
-                            ray.inv.y = copysignf(1e18f, ray.dir.y);
-                        if (!(fabsf(ray.inv.z) < 1e18f))
-                            ray.inv.z = copysignf(1e18f, ray.dir.z);
-                    }
-                    negX = ray.inv.x < 0.f;
-                    negY = ray.inv.y < 0.f;
-                    negZ = ray.inv.z < 0.f;
-                    oct = (negX ? 1u : 0u) | (negY ? 2u : 0u) | (negZ ? 4u : 0u);
+                    prepare_ray(F3(p[0], p[1], p[2]), F3(p[3], p[4], p[5]), ray, sg, mode);
                     nodeVisits = triTests = 0;
                     restart();
                     float tEnter, tExit;
@@ -759,7 +550,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(5, 5)))
                 if ((grpBits & 0xffu) != 0u) {
                     const uint32_t i = static_cast<uint32_t>(__ffs(static_cast<int>(grpBits))) - 1u;
                     grpBits &= grpBits - 1u; // the lowest set bit is a pending slot
-                    const uint32_t slot = i ^ oct;
+                    const uint32_t slot = i ^ sg.oct;
                     cur = grpBase + __popc((grpBits >> 8) & ((1u << slot) - 1u));
                     have = true;
                 }
@@ -771,89 +562,20 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(5, 5)))
             }
             if (have) {
                 have = false;
-                const uint4 *rec = reinterpret_cast<const uint4 *>(wideBytes + (static_cast<size_t>(cur) << 7));
-                const uint4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3], r4 = rec[4], r5 = rec[5];
                 if (COUNT)
                     ++nodeVisits;
-                // plane distance = q * (2^exp / d) + (origin - o) / d; the "+ 0" turns a -0 offset into
-                // +0, so that no plane distance is -0 and a box that touches the origin is kept
-                const float ax = ldexpf(ray.inv.x, static_cast<int>(static_cast<int8_t>(r0.w & 0xffu)));
-                const float ay = ldexpf(ray.inv.y, static_cast<int>(static_cast<int8_t>((r0.w >> 8) & 0xffu)));
-                const float az = ldexpf(ray.inv.z, static_cast<int>(static_cast<int8_t>((r0.w >> 16) & 0xffu)));
-                const float bx = __builtin_fmaf(__uint_as_float(r0.x) - ray.pos.x, ray.inv.x, 0.f);
-                const float by = __builtin_fmaf(__uint_as_float(r0.y) - ray.pos.y, ray.inv.y, 0.f);
-                const float bz = __builtin_fmaf(__uint_as_float(r0.z) - ray.pos.z, ray.inv.z, 0.f);
-                const v2f ax2 = {ax, ax}, ay2 = {ay, ay}, az2 = {az, az};
-                const v2f bx2 = {bx, bx}, by2 = {by, by}, bz2 = {bz, bz};
-                // near / far plane bytes by the sign of the direction: [0] slots 0-3, [1] slots 4-7
-                const uint32_t qnx[2] = {negX ? r2.z : r2.x, negX ? r2.w : r2.y};
-                const uint32_t qfx[2] = {negX ? r2.x : r2.z, negX ? r2.y : r2.w};
-                const uint32_t qny[2] = {negY ? r3.z : r3.x, negY ? r3.w : r3.y};
-                const uint32_t qfy[2] = {negY ? r3.x : r3.z, negY ? r3.y : r3.w};
-                const uint32_t qnz[2] = {negZ ? r4.z : r4.x, negZ ? r4.w : r4.y};
-                const uint32_t qfz[2] = {negZ ? r4.x : r4.z, negZ ? r4.y : r4.w};
-                // A slot is kept unless it is missed beyond the rounding margin: the sign of
-                // exit - entry * (1 - margin) is shifted into `missed`, slot 7 first.
-                uint32_t missed = 0;
                 bool anyNoLimit = false;
-#pragma unroll
-                for (int pr = 3; pr >= 0; --pr) {
-                    const int h = pr >> 1, sh = 16 * (pr & 1); // slots 2 pr and 2 pr + 1
-                    auto two = [&](uint32_t w) {
-                        v2f q;
-                        q.x = static_cast<float>((w >> sh) & 0xffu);
-                        q.y = static_cast<float>((w >> (sh + 8)) & 0xffu);
-                        return q;
-                    };
-                    const v2f hnx = __builtin_elementwise_fma(two(qnx[h]), ax2, bx2);
-                    const v2f hny = __builtin_elementwise_fma(two(qny[h]), ay2, by2);
-                    const v2f hnz = __builtin_elementwise_fma(two(qnz[h]), az2, bz2);
-                    const v2f hfx = __builtin_elementwise_fma(two(qfx[h]), ax2, bx2);
-                    const v2f hfy = __builtin_elementwise_fma(two(qfy[h]), ay2, by2);
-                    const v2f hfz = __builtin_elementwise_fma(two(qfz[h]), az2, bz2);
-                    if (COUNT) { // would the slots be hit without the distance limit?
-                        const float e1 = fmaxf(fmaxf(fmaxf(hnx.y, hny.y), hnz.y), 0.f), x1 = fminf(fminf(hfx.y, hfy.y), hfz.y);
-                        const float e0 = fmaxf(fmaxf(fmaxf(hnx.x, hny.x), hnz.x), 0.f), x0 = fminf(fminf(hfx.x, hfy.x), hfz.x);
-                        anyNoLimit |= !(e1 * SLAB_SHRINK > x1) || !(e0 * SLAB_SHRINK > x0);
-                    }
-                    const float en1 = fmaxf(fmaxf(fmaxf(hnx.y, hny.y), hnz.y), 0.f);
-                    const float ex1 = fminf(fminf(fminf(hfx.y, hfy.y), hfz.y), limit);
-                    const float en0 = fmaxf(fmaxf(fmaxf(hnx.x, hny.x), hnz.x), 0.f);
-                    const float ex0 = fminf(fminf(fminf(hfx.x, hfy.x), hfz.x), limit);
-                    missed = __builtin_amdgcn_alignbit(missed, __float_as_uint(__builtin_fmaf(-SLAB_SHRINK, en1, ex1)), 31);
-                    missed = __builtin_amdgcn_alignbit(missed, __float_as_uint(__builtin_fmaf(-SLAB_SHRINK, en0, ex0)), 31);
-                }
-                const uint32_t hits = ~missed;
-                const uint32_t imask = r0.w >> 24;
-                const uint32_t leafHits = hits & r1.z & 0xffu;
-                uint32_t inner = hits & imask;
-                if (COUNT && (leafHits | inner) == 0u) {
+                const Visit vis = visit_record<COUNT>(wideBytes, cur, ray, sg, limit, anyNoLimit);
+                if (COUNT && (vis.leafC | vis.inner) == 0u) {
                     ++dbgEmpty; // visits that found nothing
                     if (anyNoLimit)
                         ++dbgEmptyLimit; // ... because of the distance limit
                 }
-                if (leafHits != 0u) {
-                    // park the triangles from the first to the last leaf slot that was hit
-                    if (r1.z & LONG_RUN) {
-                        pendW = r1.y;
-                        pendC = r1.w;
-                    } else {
-                        const uint32_t first = static_cast<uint32_t>(__ffs(static_cast<int>(leafHits))) - 1u;
-                        const uint32_t last = 31u - static_cast<uint32_t>(__clz(static_cast<int>(leafHits)));
-                        const unsigned long long offs = (static_cast<unsigned long long>(r5.y) << 32) | r5.x;
-                        const unsigned long long cnts = (static_cast<unsigned long long>(r5.w) << 32) | r5.z;
-                        const uint32_t b0 = static_cast<uint32_t>(offs >> (8u * first)) & 0xffu;
-                        const uint32_t b1 = (static_cast<uint32_t>(offs >> (8u * last)) & 0xffu) +
-                                            (static_cast<uint32_t>(cnts >> (8u * last)) & 0xffu);
-                        pendW = r1.y + b0;
-                        pendC = b1 - b0;
-                    }
+                if (vis.leafC != 0u) { // park the triangles from the first to the last leaf slot that was hit
+                    pendW = vis.leafW;
+                    pendC = vis.leafC;
                 }
-                if (inner != 0u) {
-                    // bit i of the group = slot i ^ oct: ascending bits run front to back
-                    inner = (oct & 1u) ? (((inner & 0xAAu) >> 1) | ((inner & 0x55u) << 1)) : inner;
-                    inner = (oct & 2u) ? (((inner & 0xCCu) >> 2) | ((inner & 0x33u) << 2)) : inner;
-                    inner = (oct & 4u) ? (((inner & 0xF0u) >> 4) | ((inner & 0x0Fu) << 4)) : inner;
+                if (vis.inner != 0u) {
                     if ((grpBits & 0xffu) != 0u) {
                         if (sp < LDS_DEPTH) {
                             stBase[sp * THREADS] = grpBase;
@@ -862,8 +584,8 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(5, 5)))
                             mySpill[(sp - LDS_DEPTH) * spillStride] = make_uint2(grpBase, grpBits);
                         ++sp;
                     }
-                    grpBase = r1.x;
-                    grpBits = inner | (imask << 8);
+                    grpBase = vis.childBase;
+                    grpBits = octant_order(vis.inner, sg.oct) | (vis.imask << 8);
                 }
             }
             // ---- (C) triangle phase, when it pays --------------------------------------------------
@@ -935,6 +657,17 @@ inline TraceWs trace_ws(uint32_t rayNum) {
 
 } // namespace accel
 } // namespace kk
+
+kk::accel::View kk::accel::make_view(const void *d_accel, uint32_t faceNum, uint32_t compactedNum) {
+    const Layout l = layout(faceNum, compactedNum);
+    const char *ab = static_cast<const char *>(d_accel);
+    View v;
+    v.hdr = reinterpret_cast<const Header *>(ab + l.header);
+    v.wide = reinterpret_cast<const Wide8 *>(ab + l.nodes);
+    v.recs = reinterpret_cast<const TriRec *>(ab + l.tris);
+    v.parents = reinterpret_cast<const uint32_t *>(ab + l.parents);
+    return v;
+}
 
 extern "C" size_t kk_trace_accel_bytes(uint32_t face_num, uint32_t compacted_face_num) {
     return kk::accel::layout(face_num, compacted_face_num).total;

@@ -1,0 +1,477 @@
+// The trace-side 8-wide tree (built by kk_trace_accel_build) and what a lane needs to walk it: record
+// layouts, the conservative slab test of a record, the reference's acceptance tests, the triangle
+// test, and whole-ray walks for kernels that trace one ray per lane after another (the path tracer).
+// The ray-buffer kernel in trace_accel.hip uses the same pieces inside its persistent wave loop.
+#pragma once
+#include "kk_math.h"
+#include "traverse.h"
+
+namespace kk {
+namespace accel {
+
+using trav::LEAF;
+using trav::LEAF_MASK;
+
+constexpr uint32_t EMPTY = 0xFFFFFFFFu;
+
+struct alignas(128) Wide8 {
+    float origin[3];
+    int8_t exp[3];
+    uint8_t imask;      // slots that hold a binary subtree
+    uint32_t childBase; // wide node of the first such slot; the others follow in slot order
+    uint32_t triBase;   // first TriRec of this node's leaf slots
+    uint32_t leafMask;  // bits 0-7: slots that hold a leaf; LONG_RUN: off / cnt do not fit a byte
+    uint32_t triTotal;  // triangles of all leaf slots
+    uint8_t q[6][8];    // minx[8] maxx[8] miny[8] maxy[8] minz[8] maxz[8]
+    uint8_t off[8];     // first triangle of a leaf slot, relative to triBase
+    uint8_t cnt[8];     // its triangle count
+    uint32_t spare[8];
+};
+static_assert(sizeof(Wide8) == 128, "one cache line");
+constexpr uint32_t LONG_RUN = 0x100u;
+
+struct alignas(16) TriRec {
+    float v0[3];
+    uint32_t fi;
+    float v1[3];
+    uint32_t parent; // binary node whose child is this triangle's leaf
+    float v2[3];
+    uint32_t k; // position in the build's sorted face order
+};
+static_assert(sizeof(TriRec) == 48, "three 16-byte loads");
+
+struct alignas(256) Header {
+    float rootBox[6];
+    uint32_t faceNum, nodeNum;
+    const kk_lbvh_node *nodes; // the build's own nodes (parent boxes for the acceptance test)
+    uint32_t wideNum;
+};
+
+// A product (b - o) * (1 / d) is within 3 * 2^-24 of the reference's fl((b - o) / d) (one rounding
+// each in 1 / d, the product, and the quotient it stands for); min / max keep the bound.
+constexpr float SLAB_REL = 1e-6f, SLAB_ABS = 1e-30f;
+constexpr float SLAB_SHRINK = 1.f - 1e-6f; // the same margin as a factor on the entry distance
+
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+
+
+struct RayState {
+    f3 pos, dir, inv;
+};
+
+// Does `r` pass the slab test of the build's node `parent`, as the reference computes it?
+__device__ __forceinline__ bool passes_parent(const kk_lbvh_node *__restrict__ nodes, uint32_t parent,
+                                              const RayState &r) {
+    const trav::NodeData nd = trav::load_node(nodes, parent);
+    const float h0 = (nd.box.minPos.x - r.pos.x) * r.inv.x, h1 = (nd.box.maxPos.x - r.pos.x) * r.inv.x;
+    const float h2 = (nd.box.minPos.y - r.pos.y) * r.inv.y, h3 = (nd.box.maxPos.y - r.pos.y) * r.inv.y;
+    const float h4 = (nd.box.minPos.z - r.pos.z) * r.inv.z, h5 = (nd.box.maxPos.z - r.pos.z) * r.inv.z;
+    float en = fmaxf(fmaxf(fminf(h0, h1), fminf(h2, h3)), fminf(h4, h5));
+    const float ex = fminf(fminf(fmaxf(h0, h1), fmaxf(h2, h3)), fmaxf(h4, h5));
+    en = fmaxf(en, 0.f);
+    const float m = SLAB_REL * fmaxf(en, fabsf(ex)) + SLAB_ABS;
+    if (en <= ex - m)
+        return true;
+    if (en > ex + m)
+        return false;
+    Ray ray{r.pos, r.dir};
+    float tEnter, tExit;
+    HitAABB(ray, nd.box, tEnter, tExit);
+    return !(tEnter > tExit);
+}
+
+// Does `r` pass the reference's slab test of node `p` and of every node above it?
+__device__ __forceinline__ bool passes_chain(const kk_lbvh_node *__restrict__ nodes,
+                                             const uint32_t *__restrict__ parents, uint32_t p,
+                                             const RayState &r) {
+    const Ray ray{r.pos, r.dir};
+    while (p != EMPTY) {
+        const trav::NodeData nd = trav::load_node(nodes, p);
+        float tEnter, tExit;
+        HitAABB(ray, nd.box, tEnter, tExit);
+        if (tEnter > tExit)
+            return false;
+        p = parents[p];
+    }
+    return true;
+}
+
+enum : uint32_t { MODE_FAST = 0, MODE_CAREFUL = 1, MODE_CHAIN = 2 };
+
+// Triangles [k0, k0 + n) against the ray. Normally a better hit is taken at once and whether its
+// leaf's parent box passes the reference's slab test is checked once, for the final hit, when the ray
+// retires (MODE_FAST). A ray being re-traced after that check failed checks every hit it takes
+// (MODE_CAREFUL); a ray with a zero direction component checks the whole chain of boxes (MODE_CHAIN).
+//
+// WATERTIGHT replaces the reference's Moeller-Trumbore test by the shear-and-scale test of Woop,
+// Benthin and Wald (2013), two-sided, with its double-precision fallback on an edge: a ray through a
+// shared edge or vertex cannot slip between two triangles. It is an option, not the default, because
+// its hit / miss decisions differ from the reference's on grazing rays.
+struct Shear {
+    int kx, ky, kz;
+    float sx, sy, sz;
+};
+__device__ __forceinline__ Shear make_shear(f3 d) {
+    Shear s;
+    const float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
+    s.kz = (ax > ay) ? (ax > az ? 0 : 2) : (ay > az ? 1 : 2);
+    s.kx = s.kz + 1 == 3 ? 0 : s.kz + 1;
+    s.ky = s.kx + 1 == 3 ? 0 : s.kx + 1;
+    if (d[s.kz] < 0.f) {
+        const int t = s.kx;
+        s.kx = s.ky;
+        s.ky = t;
+    }
+    s.sx = d[s.kx] / d[s.kz];
+    s.sy = d[s.ky] / d[s.kz];
+    s.sz = 1.f / d[s.kz];
+    return s;
+}
+// returns t (< 0: miss); bx, by = weights of v1 and v2 like the reference's barycentrics
+__device__ __forceinline__ float hit_watertight(const Shear &s, f3 org, f3 v0, f3 v1, f3 v2, float &bx,
+                                                float &by) {
+    const f3 A = v0 - org, B = v1 - org, C = v2 - org;
+    const float Ax = A[s.kx] - s.sx * A[s.kz], Ay = A[s.ky] - s.sy * A[s.kz];
+    const float Bx = B[s.kx] - s.sx * B[s.kz], By = B[s.ky] - s.sy * B[s.kz];
+    const float Cx = C[s.kx] - s.sx * C[s.kz], Cy = C[s.ky] - s.sy * C[s.kz];
+    float U = Cx * By - Cy * Bx, V = Ax * Cy - Ay * Cx, W = Bx * Ay - By * Ax;
+    if (U == 0.f || V == 0.f || W == 0.f) {
+        U = static_cast<float>(static_cast<double>(Cx) * By - static_cast<double>(Cy) * Bx);
+        V = static_cast<float>(static_cast<double>(Ax) * Cy - static_cast<double>(Ay) * Cx);
+        W = static_cast<float>(static_cast<double>(Bx) * Ay - static_cast<double>(By) * Ax);
+    }
+    if ((U < 0.f || V < 0.f || W < 0.f) && (U > 0.f || V > 0.f || W > 0.f))
+        return -1.f;
+    const float det = U + V + W;
+    if (det == 0.f)
+        return -1.f;
+    const float Az = s.sz * A[s.kz], Bz = s.sz * B[s.kz], Cz = s.sz * C[s.kz];
+    const float T = U * Az + V * Bz + W * Cz;
+    const float inv = 1.f / det;
+    const float t = T * inv;
+    if (!(t >= 0.f))
+        return -1.f;
+    bx = V * inv;
+    by = W * inv;
+    return t;
+}
+
+struct Hit8 {
+    float t, bx, by;
+    uint32_t fi; // face index, 0xFFFFFFFF = miss
+    uint32_t k;  // position in the sorted face order: the smaller one wins among equal t
+    uint32_t w;  // its TriRec
+};
+
+template <bool COUNT, bool WATERTIGHT>
+__device__ __forceinline__ void test_run(const TriRec *__restrict__ recs,
+                                         const kk_lbvh_node *__restrict__ nodes,
+                                         const uint32_t *__restrict__ parents, const RayState &r,
+                                         uint32_t mode, uint32_t w0, uint32_t n, Hit8 &best,
+                                         uint32_t &triTests) {
+    const Ray ray{r.pos, r.dir};
+    Shear shear{};
+    if (WATERTIGHT && n != 0u)
+        shear = make_shear(r.dir);
+    for (uint32_t w = w0; w < w0 + n; ++w) {
+        const uint4 *p = reinterpret_cast<const uint4 *>(recs + w);
+        const uint4 a = p[0], b = p[1], c = p[2];
+        float bx = 0.f, by = 0.f;
+        const f3 v0 = F3(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z));
+        const f3 v1 = F3(__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z));
+        const f3 v2 = F3(__uint_as_float(c.x), __uint_as_float(c.y), __uint_as_float(c.z));
+        const float t = WATERTIGHT ? hit_watertight(shear, r.pos, v0, v1, v2, bx, by)
+                                   : HitTriangle(ray, v0, v1, v2, bx, by);
+        if (COUNT)
+            ++triTests;
+        if (t >= 0.f && (t < best.t || (t == best.t && c.w < best.k))) {
+            if (mode == MODE_FAST || (mode == MODE_CAREFUL ? passes_parent(nodes, b.w, r)
+                                                           : passes_chain(nodes, parents, b.w, r))) {
+                best.t = t;
+                best.bx = bx;
+                best.by = by;
+                best.fi = a.w;
+                best.k = c.w;
+                best.w = w;
+            }
+        }
+    }
+}
+
+// ---- one ray -----------------------------------------------------------------------------------------
+
+// Reciprocal direction, near-plane signs, octant and acceptance mode of a ray. A zero / denormal / NaN
+// component makes the ray irregular: its reciprocal is replaced by +-1e18 (finite stand-ins keep the
+// walk a superset of the reference's visits: inside a slab -> (-huge, +huge), outside -> both the same
+// sign) and every hit is checked against the whole chain of boxes (MODE_CHAIN).
+struct RaySigns {
+    bool negX, negY, negZ;
+    uint32_t oct; // negX | negY << 1 | negZ << 2
+};
+__device__ __forceinline__ void prepare_ray(f3 pos, f3 dir, RayState &ray, RaySigns &sg, uint32_t &mode) {
+    ray.pos = pos;
+    ray.dir = dir;
+    ray.inv = 1.f / dir;
+    const bool regular = fabsf(ray.inv.x) < 1e18f && fabsf(ray.inv.y) < 1e18f && fabsf(ray.inv.z) < 1e18f;
+    mode = MODE_FAST;
+    if (!regular) {
+        mode = MODE_CHAIN;
+        if (!(fabsf(ray.inv.x) < 1e18f))
+            ray.inv.x = copysignf(1e18f, ray.dir.x);
+        if (!(fabsf(ray.inv.y) < 1e18f))
+            ray.inv.y = copysignf(1e18f, ray.dir.y);
+        if (!(fabsf(ray.inv.z) < 1e18f))
+            ray.inv.z = copysignf(1e18f, ray.dir.z);
+    }
+    sg.negX = ray.inv.x < 0.f;
+    sg.negY = ray.inv.y < 0.f;
+    sg.negZ = ray.inv.z < 0.f;
+    sg.oct = (sg.negX ? 1u : 0u) | (sg.negY ? 2u : 0u) | (sg.negZ ? 4u : 0u);
+}
+
+// What a visit of one record found.
+struct Visit {
+    uint32_t inner;        // hit slots that hold subtrees, bit = slot
+    uint32_t imask;        // all subtree slots of the record
+    uint32_t childBase;    // wide node of the first subtree slot
+    uint32_t leafW, leafC; // triangle records from the first to the last hit leaf slot (leafC == 0: none)
+};
+
+// Slab tests of the eight slots of record `cur` against the ray, conservative: a slot is dropped only
+// when it is missed beyond the rounding margin or entered beyond `limit`. DIAG also reports whether
+// any slot would be hit without the limit.
+template <bool DIAG>
+__device__ __forceinline__ Visit visit_record(const char *__restrict__ wideBytes, uint32_t cur,
+                                              const RayState &ray, const RaySigns &sg, float limit,
+                                              bool &anyNoLimit) {
+    const uint4 *rec = reinterpret_cast<const uint4 *>(wideBytes + (static_cast<size_t>(cur) << 7));
+    const uint4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3], r4 = rec[4], r5 = rec[5];
+    // plane distance = q * (2^exp / d) + (origin - o) / d; the "+ 0" turns a -0 offset into
+    // +0, so that no plane distance is -0 and a box that touches the origin is kept
+    const float ax = ldexpf(ray.inv.x, static_cast<int>(static_cast<int8_t>(r0.w & 0xffu)));
+    const float ay = ldexpf(ray.inv.y, static_cast<int>(static_cast<int8_t>((r0.w >> 8) & 0xffu)));
+    const float az = ldexpf(ray.inv.z, static_cast<int>(static_cast<int8_t>((r0.w >> 16) & 0xffu)));
+    const float bx = __builtin_fmaf(__uint_as_float(r0.x) - ray.pos.x, ray.inv.x, 0.f);
+    const float by = __builtin_fmaf(__uint_as_float(r0.y) - ray.pos.y, ray.inv.y, 0.f);
+    const float bz = __builtin_fmaf(__uint_as_float(r0.z) - ray.pos.z, ray.inv.z, 0.f);
+    const v2f ax2 = {ax, ax}, ay2 = {ay, ay}, az2 = {az, az};
+    const v2f bx2 = {bx, bx}, by2 = {by, by}, bz2 = {bz, bz};
+    // near / far plane bytes by the sign of the direction: [0] slots 0-3, [1] slots 4-7
+    const uint32_t qnx[2] = {sg.negX ? r2.z : r2.x, sg.negX ? r2.w : r2.y};
+    const uint32_t qfx[2] = {sg.negX ? r2.x : r2.z, sg.negX ? r2.y : r2.w};
+    const uint32_t qny[2] = {sg.negY ? r3.z : r3.x, sg.negY ? r3.w : r3.y};
+    const uint32_t qfy[2] = {sg.negY ? r3.x : r3.z, sg.negY ? r3.y : r3.w};
+    const uint32_t qnz[2] = {sg.negZ ? r4.z : r4.x, sg.negZ ? r4.w : r4.y};
+    const uint32_t qfz[2] = {sg.negZ ? r4.x : r4.z, sg.negZ ? r4.y : r4.w};
+    // A slot is kept unless it is missed beyond the rounding margin: the sign of
+    // exit - entry * (1 - margin) is shifted into `missed`, slot 7 first.
+    uint32_t missed = 0;
+#pragma unroll
+    for (int pr = 3; pr >= 0; --pr) {
+        const int h = pr >> 1, sh = 16 * (pr & 1); // slots 2 pr and 2 pr + 1
+        auto two = [&](uint32_t w) {
+            v2f q;
+            q.x = static_cast<float>((w >> sh) & 0xffu);
+            q.y = static_cast<float>((w >> (sh + 8)) & 0xffu);
+            return q;
+        };
+        const v2f hnx = __builtin_elementwise_fma(two(qnx[h]), ax2, bx2);
+        const v2f hny = __builtin_elementwise_fma(two(qny[h]), ay2, by2);
+        const v2f hnz = __builtin_elementwise_fma(two(qnz[h]), az2, bz2);
+        const v2f hfx = __builtin_elementwise_fma(two(qfx[h]), ax2, bx2);
+        const v2f hfy = __builtin_elementwise_fma(two(qfy[h]), ay2, by2);
+        const v2f hfz = __builtin_elementwise_fma(two(qfz[h]), az2, bz2);
+        const float en1 = fmaxf(fmaxf(fmaxf(hnx.y, hny.y), hnz.y), 0.f);
+        const float en0 = fmaxf(fmaxf(fmaxf(hnx.x, hny.x), hnz.x), 0.f);
+        const float far1 = fminf(fminf(hfx.y, hfy.y), hfz.y), far0 = fminf(fminf(hfx.x, hfy.x), hfz.x);
+        if (DIAG)
+            anyNoLimit |= !(en1 * SLAB_SHRINK > far1) || !(en0 * SLAB_SHRINK > far0);
+        const float ex1 = fminf(far1, limit), ex0 = fminf(far0, limit);
+        missed = __builtin_amdgcn_alignbit(missed, __float_as_uint(__builtin_fmaf(-SLAB_SHRINK, en1, ex1)), 31);
+        missed = __builtin_amdgcn_alignbit(missed, __float_as_uint(__builtin_fmaf(-SLAB_SHRINK, en0, ex0)), 31);
+    }
+    const uint32_t hits = ~missed;
+    Visit v;
+    v.imask = r0.w >> 24;
+    v.childBase = r1.x;
+    v.inner = hits & v.imask;
+    v.leafW = v.leafC = 0u;
+    const uint32_t leafHits = hits & r1.z & 0xffu;
+    if (leafHits != 0u) {
+        if (r1.z & LONG_RUN) {
+            v.leafW = r1.y;
+            v.leafC = r1.w;
+        } else {
+            const uint32_t first = static_cast<uint32_t>(__ffs(static_cast<int>(leafHits))) - 1u;
+            const uint32_t last = 31u - static_cast<uint32_t>(__clz(static_cast<int>(leafHits)));
+            const unsigned long long offs = (static_cast<unsigned long long>(r5.y) << 32) | r5.x;
+            const unsigned long long cnts = (static_cast<unsigned long long>(r5.w) << 32) | r5.z;
+            const uint32_t b0 = static_cast<uint32_t>(offs >> (8u * first)) & 0xffu;
+            const uint32_t b1 = (static_cast<uint32_t>(offs >> (8u * last)) & 0xffu) +
+                                (static_cast<uint32_t>(cnts >> (8u * last)) & 0xffu);
+            v.leafW = r1.y + b0;
+            v.leafC = b1 - b0;
+        }
+    }
+    return v;
+}
+
+// bit i of the result = slot i ^ oct of `slots`: ascending bits run front to back for the ray's octant
+__device__ __forceinline__ uint32_t octant_order(uint32_t slots, uint32_t oct) {
+    slots = (oct & 1u) ? (((slots & 0xAAu) >> 1) | ((slots & 0x55u) << 1)) : slots;
+    slots = (oct & 2u) ? (((slots & 0xCCu) >> 2) | ((slots & 0x33u) << 2)) : slots;
+    slots = (oct & 4u) ? (((slots & 0xF0u) >> 4) | ((slots & 0x0Fu) << 4)) : slots;
+    return slots;
+}
+
+// ---- whole-ray walks for kernels that give each lane one ray after another ----------------------------
+
+// Device pointers into an accel buffer (made on the host by make_view, trace_accel.hip).
+struct View {
+    const Header *hdr;
+    const Wide8 *wide;
+    const TriRec *recs;
+    const uint32_t *parents;
+};
+View make_view(const void *d_accel, uint32_t faceNum, uint32_t compactedNum);
+
+// A lane's stack of groups: LANE_LDS_DEPTH entries in LDS (entry e of the lane at base[e * stride],
+// bits[e * stride]), the rest - a tree deeper than that many wide levels along one path - in private
+// memory. A walk pushes at most one group per wide level and a wide path is at most 32 levels.
+constexpr int LANE_LDS_DEPTH = 16, LANE_DEPTH = 34;
+struct LaneStack {
+    uint32_t *base;
+    unsigned short *bits;
+    int stride;
+};
+
+struct LaneWalk {
+    uint32_t grpBase, grpBits;
+    int sp;
+    uint2 deep[LANE_DEPTH - LANE_LDS_DEPTH];
+    __device__ __forceinline__ void start(uint32_t oct) {
+        sp = 0;
+        grpBase = 0u;
+        grpBits = (1u << (0u ^ oct)) | (1u << 8); // the root: slot 0 of a node whose only subtree is slot 0
+    }
+    // next record to visit; false when the walk is over
+    __device__ __forceinline__ bool next(const LaneStack &st, uint32_t oct, uint32_t &cur) {
+        if ((grpBits & 0xffu) == 0u) {
+            if (sp == 0)
+                return false;
+            --sp;
+            if (sp < LANE_LDS_DEPTH) {
+                grpBase = st.base[sp * st.stride];
+                grpBits = st.bits[sp * st.stride];
+            } else {
+                grpBase = deep[sp - LANE_LDS_DEPTH].x;
+                grpBits = deep[sp - LANE_LDS_DEPTH].y;
+            }
+        }
+        const uint32_t i = static_cast<uint32_t>(__ffs(static_cast<int>(grpBits))) - 1u;
+        grpBits &= grpBits - 1u; // the lowest set bit is a pending slot
+        cur = grpBase + __popc((grpBits >> 8) & ((1u << (i ^ oct)) - 1u));
+        return true;
+    }
+    // the subtree hits of a visit become the current group; the rest of the old one waits
+    __device__ __forceinline__ void enter(const LaneStack &st, const Visit &v, uint32_t oct) {
+        if (v.inner == 0u)
+            return;
+        if ((grpBits & 0xffu) != 0u) {
+            if (sp < LANE_LDS_DEPTH) {
+                st.base[sp * st.stride] = grpBase;
+                st.bits[sp * st.stride] = static_cast<unsigned short>(grpBits);
+            } else if (sp < LANE_DEPTH)
+                deep[sp - LANE_LDS_DEPTH] = make_uint2(grpBase, grpBits);
+            ++sp;
+        }
+        grpBase = v.childBase;
+        grpBits = octant_order(v.inner, oct) | (v.imask << 8);
+    }
+};
+
+// Closest hit of one ray: the result of the reference's rayCastLBVH (see trace_accel.hip for why).
+__device__ __forceinline__ Hit8 closest_hit_lane(const View &v, Ray r, const LaneStack &st) {
+    Hit8 best;
+    best.t = FloatMax;
+    best.bx = best.by = 0.f;
+    best.fi = best.k = best.w = 0xFFFFFFFFu;
+    AABB rootBox;
+    rootBox.minPos = {v.hdr->rootBox[0], v.hdr->rootBox[1], v.hdr->rootBox[2]};
+    rootBox.maxPos = {v.hdr->rootBox[3], v.hdr->rootBox[4], v.hdr->rootBox[5]};
+    float tEnter, tExit;
+    HitAABB(r, rootBox, tEnter, tExit);
+    if (tEnter > tExit)
+        return best;
+    const kk_lbvh_node *nodes = v.hdr->nodes;
+    const char *wideBytes = reinterpret_cast<const char *>(v.wide);
+    RayState ray;
+    RaySigns sg;
+    uint32_t mode;
+    prepare_ray(r.pos, r.dir, ray, sg, mode);
+    uint32_t unused = 0;
+    bool unusedFlag = false;
+    LaneWalk w;
+    while (true) { // a second walk only when the final hit of the first fails its parent-box test
+        best.t = FloatMax;
+        best.bx = best.by = 0.f;
+        best.fi = best.k = best.w = 0xFFFFFFFFu;
+        w.start(sg.oct);
+        uint32_t cur;
+        while (w.next(st, sg.oct, cur)) {
+            const float limit = best.t + trav::CULL_SLACK * best.t;
+            const Visit vis = visit_record<false>(wideBytes, cur, ray, sg, limit, unusedFlag);
+            test_run<false, false>(v.recs, nodes, v.parents, ray, mode, vis.leafW, vis.leafC, best, unused);
+            w.enter(st, vis, sg.oct);
+        }
+        if (best.fi != 0xFFFFFFFFu && mode == MODE_FAST && !passes_parent(nodes, v.recs[best.w].parent, ray)) {
+            mode = MODE_CAREFUL;
+            continue;
+        }
+        return best;
+    }
+}
+
+// True when the reference's closest hit of `r` is nearer than tMax: some triangle whose leaf's boxes
+// the ray passes is hit at 0 <= t < tMax.
+__device__ __forceinline__ bool occluded_lane(const View &v, Ray r, float tMax, const LaneStack &st) {
+    AABB rootBox;
+    rootBox.minPos = {v.hdr->rootBox[0], v.hdr->rootBox[1], v.hdr->rootBox[2]};
+    rootBox.maxPos = {v.hdr->rootBox[3], v.hdr->rootBox[4], v.hdr->rootBox[5]};
+    float tEnter, tExit;
+    HitAABB(r, rootBox, tEnter, tExit);
+    if (tEnter > tExit)
+        return false;
+    const kk_lbvh_node *nodes = v.hdr->nodes;
+    const char *wideBytes = reinterpret_cast<const char *>(v.wide);
+    RayState ray;
+    RaySigns sg;
+    uint32_t mode;
+    prepare_ray(r.pos, r.dir, ray, sg, mode);
+    const float limit = tMax + trav::CULL_SLACK * tMax;
+    bool unusedFlag = false;
+    LaneWalk w;
+    w.start(sg.oct);
+    uint32_t cur;
+    while (w.next(st, sg.oct, cur)) {
+        const Visit vis = visit_record<false>(wideBytes, cur, ray, sg, limit, unusedFlag);
+        for (uint32_t t3 = vis.leafW; t3 < vis.leafW + vis.leafC; ++t3) {
+            const uint4 *p = reinterpret_cast<const uint4 *>(v.recs + t3);
+            const uint4 a = p[0], b = p[1], c = p[2];
+            float bx, by;
+            const float t = HitTriangle(r, F3(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z)),
+                                        F3(__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z)),
+                                        F3(__uint_as_float(c.x), __uint_as_float(c.y), __uint_as_float(c.z)), bx, by);
+            if (t >= 0.f && t < tMax &&
+                (mode == MODE_CHAIN ? passes_chain(nodes, v.parents, b.w, ray) : passes_parent(nodes, b.w, ray)))
+                return true;
+        }
+        w.enter(st, vis, sg.oct);
+    }
+    return false;
+}
+
+} // namespace accel
+} // namespace kk

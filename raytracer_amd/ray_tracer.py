@@ -138,7 +138,9 @@ class _PtScene(C.Structure):
                 ("inv_proj", C.c_float * 16), ("triangles", C.c_void_p),
                 ("tri_to_position_indices", C.c_void_p), ("positions", C.c_void_p),
                 ("normals", C.c_void_p), ("tex_coords", C.c_void_p), ("lights", C.c_void_p),
-                ("materials", C.c_void_p), ("light_tot_area", C.c_float), ("_pad2", C.c_uint32)]
+                ("materials", C.c_void_p), ("light_tot_area", C.c_float), ("_pad2", C.c_uint32),
+                ("trace_accel", C.c_void_p), ("accel_face_num", C.c_uint32),
+                ("accel_compacted_face_num", C.c_uint32)]
 
 
 class _PtFrame(C.Structure):
@@ -233,6 +235,8 @@ class RayTracer:
                             "materials": materials}
         self._modified = True
 
+    use_trace_tree = True  # walk the 8-wide trace-side tree (same image); False: the binary tree as built
+
     def SetLBVH(self, lbvh: LBVH):
         self.lbvh = lbvh
 
@@ -303,6 +307,11 @@ class RayTracer:
             return
         y0, y1 = rows if rows is not None else (0, fb.height)
         with torch.cuda.device(self.device):
+            if self.use_trace_tree:
+                self._scene.trace_accel = self.lbvh.trace_accel().data_ptr()
+                self._scene.accel_face_num, self._scene.accel_compacted_face_num = self.lbvh._accel_sizes
+            else:
+                self._scene.trace_accel = None
             _lib.check(_lib.lib().kk_pt_render_sample(
                 self.lbvh.GetDeivceDataDevicePtr(), C.byref(self._scene), C.byref(self._frame),
                 self.d_accum.data_ptr(), fb.rgba.data_ptr(), fb.width, fb.height, int(y0), int(y1),

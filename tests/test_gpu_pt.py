@@ -73,6 +73,22 @@ def test_radiance_matches_checker(oracle, veach, W, H, spp):
     assert float((np.abs(img.astype(int) - ref_img.astype(int)).max(axis=2) > 1).mean()) <= 2e-3
 
 
+def test_both_trees_give_the_same_bits(veach):
+    """The path tracer walks the 8-wide trace-side tree by default; on the binary tree as built it must
+    accumulate exactly the same radiance (same hits, same shadow-ray answers, same random draws)."""
+    W, H, spp = 240, 135, 3
+    out = {}
+    for wide in (True, False):
+        tracer, *_ = _setup(veach, W, H)
+        tracer.use_trace_tree = wide
+        fb = FrameBuffer(W, H, DEV)
+        for _ in range(spp):
+            tracer.Render(fb)
+        torch.cuda.synchronize()
+        out[wide] = (tracer.d_accum.cpu().numpy().tobytes(), fb.ReadBack().tobytes())
+    assert out[True] == out[False]
+
+
 def test_row_split_gives_the_same_image(veach):
     W, H = 160, 100
     tracer, arr, c, proj = _setup(veach, W, H)
