@@ -458,6 +458,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(5, 5)))
         best.t = FloatMax;
         best.bx = best.by = 0.f;
         best.fi = best.k = best.w = 0xFFFFFFFFu;
+        best.sure = false;
         sp = 0;
         pendC = 0u;
         // a group that holds just the root: slot 0 of a node whose only internal slot is slot 0
@@ -471,7 +472,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(5, 5)))
         // ---- retire finished rays, refill idle lanes ------------------------------------------------
         if (finished) {
             bool ok = true;
-            if (best.fi != 0xFFFFFFFFu && mode == MODE_FAST)
+            if (best.fi != 0xFFFFFFFFu && mode == MODE_FAST && !best.sure)
                 ok = passes_parent(nodes, recs[best.w].parent, ray);
             finished = false;
             if (ok) {

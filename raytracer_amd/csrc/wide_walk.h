@@ -61,13 +61,12 @@ struct RayState {
     f3 pos, dir, inv;
 };
 
-// Does `r` pass the slab test of the build's node `parent`, as the reference computes it?
-__device__ __forceinline__ bool passes_parent(const kk_lbvh_node *__restrict__ nodes, uint32_t parent,
-                                              const RayState &r) {
-    const trav::NodeData nd = trav::load_node(nodes, parent);
-    const float h0 = (nd.box.minPos.x - r.pos.x) * r.inv.x, h1 = (nd.box.maxPos.x - r.pos.x) * r.inv.x;
-    const float h2 = (nd.box.minPos.y - r.pos.y) * r.inv.y, h3 = (nd.box.maxPos.y - r.pos.y) * r.inv.y;
-    const float h4 = (nd.box.minPos.z - r.pos.z) * r.inv.z, h5 = (nd.box.maxPos.z - r.pos.z) * r.inv.z;
+// Does `r` pass the slab test of `box`, as the reference computes it? Decided by the reciprocal form
+// when that is clear of its rounding margin, by the reference's divisions otherwise.
+__device__ __forceinline__ bool passes_box(const AABB &box, const RayState &r) {
+    const float h0 = (box.minPos.x - r.pos.x) * r.inv.x, h1 = (box.maxPos.x - r.pos.x) * r.inv.x;
+    const float h2 = (box.minPos.y - r.pos.y) * r.inv.y, h3 = (box.maxPos.y - r.pos.y) * r.inv.y;
+    const float h4 = (box.minPos.z - r.pos.z) * r.inv.z, h5 = (box.maxPos.z - r.pos.z) * r.inv.z;
     float en = fmaxf(fmaxf(fminf(h0, h1), fminf(h2, h3)), fminf(h4, h5));
     const float ex = fminf(fminf(fmaxf(h0, h1), fmaxf(h2, h3)), fmaxf(h4, h5));
     en = fmaxf(en, 0.f);
@@ -78,8 +77,14 @@ __device__ __forceinline__ bool passes_parent(const kk_lbvh_node *__restrict__ n
         return false;
     Ray ray{r.pos, r.dir};
     float tEnter, tExit;
-    HitAABB(ray, nd.box, tEnter, tExit);
+    HitAABB(ray, box, tEnter, tExit);
     return !(tEnter > tExit);
+}
+
+// Does `r` pass the slab test of the build's node `parent`, as the reference computes it?
+__device__ __forceinline__ bool passes_parent(const kk_lbvh_node *__restrict__ nodes, uint32_t parent,
+                                              const RayState &r) {
+    return passes_box(trav::load_node(nodes, parent).box, r);
 }
 
 // Does `r` pass the reference's slab test of node `p` and of every node above it?
@@ -163,6 +168,10 @@ struct Hit8 {
     uint32_t fi; // face index, 0xFFFFFFFF = miss
     uint32_t k;  // position in the sorted face order: the smaller one wins among equal t
     uint32_t w;  // its TriRec
+    // The ray passes the reference's slab test of the triangle's own bounding box. The leaf's parent
+    // box contains that box and the test is monotonic in the box, so the parent-box test (and with it
+    // every test above) is known to pass without loading the parent.
+    bool sure;
 };
 
 template <bool COUNT, bool WATERTIGHT>
@@ -195,6 +204,12 @@ __device__ __forceinline__ void test_run(const TriRec *__restrict__ recs,
                 best.fi = a.w;
                 best.k = c.w;
                 best.w = w;
+                if (mode == MODE_FAST) {
+                    AABB tb;
+                    tb.minPos = {fminf(fminf(v0.x, v1.x), v2.x), fminf(fminf(v0.y, v1.y), v2.y), fminf(fminf(v0.z, v1.z), v2.z)};
+                    tb.maxPos = {fmaxf(fmaxf(v0.x, v1.x), v2.x), fmaxf(fmaxf(v0.y, v1.y), v2.y), fmaxf(fmaxf(v0.z, v1.z), v2.z)};
+                    best.sure = passes_box(tb, r);
+                }
             }
         }
     }
@@ -398,6 +413,7 @@ __device__ __forceinline__ Hit8 closest_hit_lane(const View &v, Ray r, const Lan
     best.t = FloatMax;
     best.bx = best.by = 0.f;
     best.fi = best.k = best.w = 0xFFFFFFFFu;
+    best.sure = false;
     AABB rootBox;
     rootBox.minPos = {v.hdr->rootBox[0], v.hdr->rootBox[1], v.hdr->rootBox[2]};
     rootBox.maxPos = {v.hdr->rootBox[3], v.hdr->rootBox[4], v.hdr->rootBox[5]};
@@ -426,7 +442,8 @@ __device__ __forceinline__ Hit8 closest_hit_lane(const View &v, Ray r, const Lan
             test_run<false, false>(v.recs, nodes, v.parents, ray, mode, vis.leafW, vis.leafC, best, unused);
             w.enter(st, vis, sg.oct);
         }
-        if (best.fi != 0xFFFFFFFFu && mode == MODE_FAST && !passes_parent(nodes, v.recs[best.w].parent, ray)) {
+        if (best.fi != 0xFFFFFFFFu && mode == MODE_FAST && !best.sure &&
+            !passes_parent(nodes, v.recs[best.w].parent, ray)) {
             mode = MODE_CAREFUL;
             continue;
         }
