@@ -138,8 +138,9 @@ __global__ __launch_bounds__(THREADS) void classify_kernel(const T *__restrict__
 // ("not in an empty scalar range") is packed into rows along x, y and z, so the inward march of a
 // depth-shell voxel - "first position whose 3 x 3 window holds a non-empty voxel" - is the OR of nine
 // row masks and a count of trailing / leading zeros.
+constexpr int FILL_THREADS = 1024; // one workgroup per brick: many threads hide the latency of its loads
 template <typename T>
-__global__ __launch_bounds__(THREADS) void fill_atlas_lds_kernel(const T *__restrict__ vol, int dx,
+__global__ __launch_bounds__(FILL_THREADS) void fill_atlas_lds_kernel(const T *__restrict__ vol, int dx,
                                                                  int dy, int dz,
                                                                  const kk_vdb_node *__restrict__ leaves,
                                                                  int B, int apronWid, int apronDepWid,
@@ -154,20 +155,20 @@ __global__ __launch_bounds__(THREADS) void fill_atlas_lds_kernel(const T *__rest
     T *__restrict__ out = atlas + brickVox * blockIdx.x;
     const bool depthBox = apronDepWid != apronWid;
     const int tid = threadIdx.x;
-    for (int v = tid; v < static_cast<int>(brickVox); v += THREADS) {
+    for (int v = tid; v < static_cast<int>(brickVox); v += FILL_THREADS) {
         const int ax = v % A, ay = (v / A) % A, az = v / A2;
         s_vox[v] = voxelAt(vol, dx, dy, dz, leaf.pos[0] + ax - apronDepWid, leaf.pos[1] + ay - apronDepWid,
                            leaf.pos[2] + az - apronDepWid);
     }
     __syncthreads();
     if (!depthBox) {
-        for (int v = tid; v < static_cast<int>(brickVox); v += THREADS)
+        for (int v = tid; v < static_cast<int>(brickVox); v += FILL_THREADS)
             out[v] = s_vox[v];
         return;
     }
     // row r of direction d: bit i = voxel i along d is not empty. Rows are indexed [outer][inner]:
     // along x (outer z, inner y), along y (outer z, inner x), along z (outer y, inner x).
-    for (int r = tid; r < 3 * A2; r += THREADS) {
+    for (int r = tid; r < 3 * A2; r += FILL_THREADS) {
         const int d = r / A2, outer = (r % A2) / A, inner = r % A;
         int base, step;
         if (d == 0) {
@@ -187,7 +188,7 @@ __global__ __launch_bounds__(THREADS) void fill_atlas_lds_kernel(const T *__rest
     }
     __syncthreads();
     const unsigned long long field = (1ull << (B - 1)) - 1ull; // the B - 1 positions a march can stop at
-    for (int v = tid; v < static_cast<int>(brickVox); v += THREADS) {
+    for (int v = tid; v < static_cast<int>(brickVox); v += FILL_THREADS) {
         const int ax = v % A, ay = (v / A) % A, az = v / A2;
         const int dirX = ax == 0 ? 1 : ax == A - 1 ? -1 : 0;
         const int dirY = ay == 0 ? 1 : ay == A - 1 ? -1 : 0;
@@ -336,7 +337,7 @@ int fillAtlas(const T *d_volume, uint32_t dx, uint32_t dy, uint32_t dz, const kk
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
             raised[sizeof(T) - 1] = true;
         }
-        fill_atlas_lds_kernel<T><<<plan->leaf_num, THREADS, lds, static_cast<hipStream_t>(stream)>>>(
+        fill_atlas_lds_kernel<T><<<plan->leaf_num, FILL_THREADS, lds, static_cast<hipStream_t>(stream)>>>(
             d_volume, dx, dy, dz, d_node_pools + p.node_starts[0], p.dims[0], p.apron_wid,
             p.apron_dep_wid, r, d_atlas);
     } else
