@@ -179,9 +179,9 @@ def main():
         return
 
     # ---- roofline of the dominant kernel (closest_hit_accel_kernel) ---------------------------------
-    # algorithmic bytes per launch: the 96 B a visit reads of a 128-B node record + 48 B per triangle
+    # algorithmic bytes per launch: the 80 B a visit reads of a 128-B node record + 48 B per triangle
     # record tested + 4 B order index + 24 B ray in + 16 B hit out, from the kernel's own work counters
-    alg_bytes = 96 * counters["node_fetches"] + 48 * counters["tri_tests"] + (4 + 24 + 16) * R
+    alg_bytes = 80 * counters["node_fetches"] + 48 * counters["tri_tests"] + (4 + 24 + 16) * R
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
     passes = max(counters["wave_passes"], 1)
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",

@@ -299,11 +299,9 @@ __global__ __launch_bounds__(BT) void collapse_level_kernel(
         rec.imask = static_cast<uint8_t>(imask);
         rec.childBase = childBase;
         rec.triBase = triBase;
-        rec.leafMask = leafMask | (ct > 255u ? LONG_RUN : 0u);
-        rec.triTotal = ct;
+        uint32_t counts = 0, longest = 0;
         uint32_t rank = 0, run = 0;
         for (int sl = 0; sl < 8; ++sl) {
-            rec.off[sl] = rec.cnt[sl] = 0;
             const uint32_t j = (childOf >> (4 * sl)) & 0xFu;
             if (j == 0xFu) { // an empty slot cannot be hit
                 rec.q[0][sl] = rec.q[2][sl] = rec.q[4][sl] = 255;
@@ -322,8 +320,8 @@ __global__ __launch_bounds__(BT) void collapse_level_kernel(
             }
             uint32_t k0, k1;
             runOf(ref, k0, k1);
-            rec.off[sl] = static_cast<uint8_t>(run < 255u ? run : 255u);
-            rec.cnt[sl] = static_cast<uint8_t>(k1 - k0 < 255u ? k1 - k0 : 255u);
+            counts |= (k1 - k0 < 15u ? k1 - k0 : 15u) << (4 * sl);
+            longest = k1 - k0 > longest ? k1 - k0 : longest;
             const uint32_t parent = s_aux[j][tid];
             for (uint32_t k = k0; k < k1; ++k, ++run) {
                 const uint32_t fi = faces[k];
@@ -336,7 +334,9 @@ __global__ __launch_bounds__(BT) void collapse_level_kernel(
                 o[2] = make_uint4(__float_as_uint(c.x), __float_as_uint(c.y), __float_as_uint(c.z), k);
             }
         }
-        for (int i = 0; i < 8; ++i)
+        rec.leafMask = leafMask | (longest > 15u ? LONG_RUN : 0u);
+        rec.counts = longest > 15u ? ct : counts;
+        for (int i = 0; i < 12; ++i)
             rec.spare[i] = 0;
         uint4 *o = reinterpret_cast<uint4 *>(out + w);
         const uint4 *src = reinterpret_cast<const uint4 *>(&rec);

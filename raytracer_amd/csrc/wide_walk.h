@@ -19,13 +19,11 @@ struct alignas(128) Wide8 {
     int8_t exp[3];
     uint8_t imask;      // slots that hold a binary subtree
     uint32_t childBase; // wide node of the first such slot; the others follow in slot order
-    uint32_t triBase;   // first TriRec of this node's leaf slots
-    uint32_t leafMask;  // bits 0-7: slots that hold a leaf; LONG_RUN: off / cnt do not fit a byte
-    uint32_t triTotal;  // triangles of all leaf slots
+    uint32_t triBase;   // first TriRec of this node's leaf slots (stored slot after slot)
+    uint32_t leafMask;  // bits 0-7: slots that hold a leaf; LONG_RUN: some leaf has more than 15 triangles
+    uint32_t counts;    // 4 bits per slot: triangles of a leaf slot; with LONG_RUN: triangles of all leaf slots
     uint8_t q[6][8];    // minx[8] maxx[8] miny[8] maxy[8] minz[8] maxz[8]
-    uint8_t off[8];     // first triangle of a leaf slot, relative to triBase
-    uint8_t cnt[8];     // its triangle count
-    uint32_t spare[8];
+    uint32_t spare[12]; // a visit reads the first 80 bytes
 };
 static_assert(sizeof(Wide8) == 128, "one cache line");
 constexpr uint32_t LONG_RUN = 0x100u;
@@ -262,7 +260,7 @@ __device__ __forceinline__ Visit visit_record(const char *__restrict__ wideBytes
                                               const RayState &ray, const RaySigns &sg, float limit,
                                               bool &anyNoLimit) {
     const uint4 *rec = reinterpret_cast<const uint4 *>(wideBytes + (static_cast<size_t>(cur) << 7));
-    const uint4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3], r4 = rec[4], r5 = rec[5];
+    const uint4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3], r4 = rec[4];
     // plane distance = q * (2^exp / d) + (origin - o) / d; the "+ 0" turns a -0 offset into
     // +0, so that no plane distance is -0 and a box that touches the origin is kept
     const float ax = ldexpf(ray.inv.x, static_cast<int>(static_cast<int8_t>(r0.w & 0xffu)));
@@ -319,13 +317,14 @@ __device__ __forceinline__ Visit visit_record(const char *__restrict__ wideBytes
             v.leafW = r1.y;
             v.leafC = r1.w;
         } else {
+            // triangles before slot n = sum of the count nibbles below n
             const uint32_t first = static_cast<uint32_t>(__ffs(static_cast<int>(leafHits))) - 1u;
             const uint32_t last = 31u - static_cast<uint32_t>(__clz(static_cast<int>(leafHits)));
-            const unsigned long long offs = (static_cast<unsigned long long>(r5.y) << 32) | r5.x;
-            const unsigned long long cnts = (static_cast<unsigned long long>(r5.w) << 32) | r5.z;
-            const uint32_t b0 = static_cast<uint32_t>(offs >> (8u * first)) & 0xffu;
-            const uint32_t b1 = (static_cast<uint32_t>(offs >> (8u * last)) & 0xffu) +
-                                (static_cast<uint32_t>(cnts >> (8u * last)) & 0xffu);
+            auto below = [&](uint32_t n) {
+                const uint32_t x = n >= 8u ? r1.w : (r1.w & ((1u << (4u * n)) - 1u));
+                return (((x & 0x0F0F0F0Fu) + ((x >> 4) & 0x0F0F0F0Fu)) * 0x01010101u) >> 24;
+            };
+            const uint32_t b0 = below(first), b1 = below(last + 1u);
             v.leafW = r1.y + b0;
             v.leafC = b1 - b0;
         }

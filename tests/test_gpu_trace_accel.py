@@ -14,8 +14,8 @@ from raytracer_amd.lbvh import LBVH  # noqa: E402
 
 DEV = "cuda:0"
 WIDE = np.dtype([("origin", "<f4", 3), ("exp", "i1", 3), ("imask", "u1"), ("childBase", "<u4"),
-                 ("triBase", "<u4"), ("leafMask", "<u4"), ("triTotal", "<u4"), ("q", "u1", (6, 8)),
-                 ("off", "u1", 8), ("cnt", "u1", 8), ("spare", "<u4", 8)])
+                 ("triBase", "<u4"), ("leafMask", "<u4"), ("counts", "<u4"), ("q", "u1", (6, 8)),
+                 ("spare", "<u4", 12)])
 TRI = np.dtype([("v0", "<f4", 3), ("fi", "<u4"), ("v1", "<f4", 3), ("parent", "<u4"), ("v2", "<f4", 3),
                 ("k", "<u4")])
 NODE = np.dtype([("lft", "<u4"), ("rht", "<u4"), ("box", "<f4", 6)])
@@ -62,11 +62,17 @@ def _check(bvh, pos, tri):
     assert np.array_equal(np.sort(tris["k"]), np.arange(N, dtype=np.uint32))
     faces = bvh.d_faces.cpu().numpy().view(np.uint32)
     assert np.array_equal(tris["fi"], faces[tris["k"]])
+    long_run = (wide["leafMask"] & 0x100) != 0
+    nib = (wide["counts"][:, None] >> (4 * np.arange(8, dtype=np.uint32))[None, :]) & 0xF   # [W, 8]
+    cnt = np.where(long_run[:, None], 0, nib)
+    assert (np.where(long_run[:, None], True, (cnt > 0) == (((leaf_mask[:, None] >> np.arange(8)) & 1) > 0))).all()
+    tri_total = np.where(long_run, wide["counts"], cnt.sum(axis=1)).astype(np.int64)
+    off = np.cumsum(cnt, axis=1) - cnt
     tranges = np.zeros(N + 1, np.int64)
-    np.add.at(tranges, wide["triBase"][wide["triTotal"] > 0], 1)
-    np.add.at(tranges, (wide["triBase"] + wide["triTotal"])[wide["triTotal"] > 0], -1)
+    np.add.at(tranges, wide["triBase"][tri_total > 0], 1)
+    np.add.at(tranges, (wide["triBase"] + tri_total)[tri_total > 0], -1)
     assert (np.cumsum(tranges)[:N] == 1).all()
-    assert int(wide["triTotal"].sum()) == N
+    assert int(tri_total.sum()) == N
     # vertices are the mesh's
     p = pos.reshape(-1, 3)
     t = tri.reshape(-1, 3)
@@ -88,18 +94,18 @@ def _check(bvh, pos, tri):
     org = wide["origin"].astype(np.float64)
     tri_min = np.minimum(np.minimum(tris["v0"], tris["v1"]), tris["v2"]).astype(np.float64)
     tri_max = np.maximum(np.maximum(tris["v0"], tris["v1"]), tris["v2"]).astype(np.float64)
-    short = (wide["leafMask"] & 0x100) == 0
+    short = ~long_run
     for s in range(8):
         sel = np.nonzero(((leaf_mask >> s) & 1).astype(bool) & short)[0]
         if sel.size == 0:
             continue
         lo = org[sel] + wide["q"][sel][:, 0::2, s] * scale[sel]
         hi = org[sel] + wide["q"][sel][:, 1::2, s] * scale[sel]
-        first = wide["triBase"][sel] + wide["off"][sel, s]
-        cnt = wide["cnt"][sel, s]
-        assert (cnt > 0).all()
-        for j in range(int(cnt.max())):
-            m = cnt > j
+        first = wide["triBase"][sel] + off[sel, s]
+        n_s = cnt[sel, s]
+        assert (n_s > 0).all()
+        for j in range(int(n_s.max())):
+            m = n_s > j
             assert (lo[m] <= tri_min[first[m] + j]).all() and (hi[m] >= tri_max[first[m] + j]).all()
     return W
 
