@@ -164,9 +164,10 @@ size_t kk_trace_accel_bytes(uint32_t face_num, uint32_t compacted_face_num);
 /* Where the pieces sit inside the accel buffer (byte offsets), for tools and tests that inspect it.
  * header: 6 floats root box, uint32 face_num, uint32 binary node count, the nodes pointer, uint32
  * wide node count (valid after the build). nodes: 128-byte records: float origin[3]; int8 exp[3];
- * uint8 imask; uint32 childBase, triBase, leafMask (bit 8: a leaf has more than 15 triangles),
- * counts (4 bits per slot, or with bit 8 the triangles of all leaf slots); uint8 q[6][8] (minx maxx
- * miny maxy minz maxz per slot); 48 spare bytes.
+ * uint8 imask; uint32 childBase, triBase, leafMask (bit 8: a leaf has more than 15 triangles, use
+ * off16 / cnt16; bit 9: they do not fit 16 bits, counts holds the triangles of all leaf slots),
+ * counts (4 bits per slot); uint8 q[6][8] (minx maxx miny maxy minz maxz per slot); uint16 off16[8],
+ * cnt16[8]; 16 spare bytes.
  * tris: 48-byte records: float v0[3]; uint32 face; float v1[3]; uint32 parent (binary node);
  * float v2[3]; uint32 k (sorted position). parents: uint32 per binary node. */
 typedef struct kk_trace_accel_layout_info {

@@ -302,6 +302,7 @@ __global__ __launch_bounds__(BT) void collapse_level_kernel(
         uint32_t counts = 0, longest = 0;
         uint32_t rank = 0, run = 0;
         for (int sl = 0; sl < 8; ++sl) {
+            rec.off16[sl] = rec.cnt16[sl] = 0;
             const uint32_t j = (childOf >> (4 * sl)) & 0xFu;
             if (j == 0xFu) { // an empty slot cannot be hit
                 rec.q[0][sl] = rec.q[2][sl] = rec.q[4][sl] = 255;
@@ -322,6 +323,8 @@ __global__ __launch_bounds__(BT) void collapse_level_kernel(
             runOf(ref, k0, k1);
             counts |= (k1 - k0 < 15u ? k1 - k0 : 15u) << (4 * sl);
             longest = k1 - k0 > longest ? k1 - k0 : longest;
+            rec.off16[sl] = static_cast<uint16_t>(run < 65535u ? run : 65535u);
+            rec.cnt16[sl] = static_cast<uint16_t>(k1 - k0 < 65535u ? k1 - k0 : 65535u);
             const uint32_t parent = s_aux[j][tid];
             for (uint32_t k = k0; k < k1; ++k, ++run) {
                 const uint32_t fi = faces[k];
@@ -334,9 +337,10 @@ __global__ __launch_bounds__(BT) void collapse_level_kernel(
                 o[2] = make_uint4(__float_as_uint(c.x), __float_as_uint(c.y), __float_as_uint(c.z), k);
             }
         }
-        rec.leafMask = leafMask | (longest > 15u ? LONG_RUN : 0u);
-        rec.counts = longest > 15u ? ct : counts;
-        for (int i = 0; i < 12; ++i)
+        const bool huge = ct > 65535u;
+        rec.leafMask = leafMask | (longest > 15u ? LONG_RUN : 0u) | (huge ? HUGE_RUN : 0u);
+        rec.counts = huge ? ct : counts;
+        for (int i = 0; i < 4; ++i)
             rec.spare[i] = 0;
         uint4 *o = reinterpret_cast<uint4 *>(out + w);
         const uint4 *src = reinterpret_cast<const uint4 *>(&rec);

@@ -20,13 +20,17 @@ struct alignas(128) Wide8 {
     uint8_t imask;      // slots that hold a binary subtree
     uint32_t childBase; // wide node of the first such slot; the others follow in slot order
     uint32_t triBase;   // first TriRec of this node's leaf slots (stored slot after slot)
-    uint32_t leafMask;  // bits 0-7: slots that hold a leaf; LONG_RUN: some leaf has more than 15 triangles
-    uint32_t counts;    // 4 bits per slot: triangles of a leaf slot; with LONG_RUN: triangles of all leaf slots
+    uint32_t leafMask;  // bits 0-7: slots that hold a leaf; LONG_RUN, HUGE_RUN: see counts
+    uint32_t counts;    // 4 bits per slot: triangles of a leaf slot. LONG_RUN (some leaf has more than
+                        // 15): they are in off16 / cnt16 instead. HUGE_RUN (they do not fit 16 bits
+                        // either): the triangles of all leaf slots, which are then tested together.
     uint8_t q[6][8];    // minx[8] maxx[8] miny[8] maxy[8] minz[8] maxz[8]
-    uint32_t spare[12]; // a visit reads the first 80 bytes
+    uint16_t off16[8];  // LONG_RUN only: first triangle of a leaf slot relative to triBase ...
+    uint16_t cnt16[8];  // ... and its triangle count
+    uint32_t spare[4];  // a visit reads the first 80 bytes (112 in a LONG_RUN node with a leaf hit)
 };
 static_assert(sizeof(Wide8) == 128, "one cache line");
-constexpr uint32_t LONG_RUN = 0x100u;
+constexpr uint32_t LONG_RUN = 0x100u, HUGE_RUN = 0x200u;
 
 struct alignas(16) TriRec {
     float v0[3];
@@ -313,9 +317,16 @@ __device__ __forceinline__ Visit visit_record(const char *__restrict__ wideBytes
     v.leafW = v.leafC = 0u;
     const uint32_t leafHits = hits & r1.z & 0xffu;
     if (leafHits != 0u) {
-        if (r1.z & LONG_RUN) {
+        if (r1.z & HUGE_RUN) {
             v.leafW = r1.y;
             v.leafC = r1.w;
+        } else if (r1.z & LONG_RUN) { // rare: 16-bit offsets and counts from the record's sixth and seventh piece
+            const uint32_t first = static_cast<uint32_t>(__ffs(static_cast<int>(leafHits))) - 1u;
+            const uint32_t last = 31u - static_cast<uint32_t>(__clz(static_cast<int>(leafHits)));
+            const unsigned short *oc = reinterpret_cast<const unsigned short *>(rec + 5);
+            const uint32_t b0 = oc[first], b1 = static_cast<uint32_t>(oc[last]) + oc[8 + last];
+            v.leafW = r1.y + b0;
+            v.leafC = b1 - b0;
         } else {
             // triangles before slot n = sum of the count nibbles below n
             const uint32_t first = static_cast<uint32_t>(__ffs(static_cast<int>(leafHits))) - 1u;

@@ -29,5 +29,17 @@ out = {
     "valu_lane_utilisation": c["SQ_THREAD_CYCLES_VALU"] / (c["SQ_INSTS_VALU"] * 64),
     "l2_hit_rate": c["TCC_HIT_sum"] / c["TCC_REQ_sum"],
 }
+if "GRBM_GUI_ACTIVE" in c:
+    # vector-memory path: busy cycles summed over the 256 CUs' units against the kernel's cycles
+    # (GRBM_GUI_ACTIVE is summed over the 8 XCDs)
+    cycles = c["GRBM_GUI_ACTIVE"] / 8
+    out["texture_path"] = {
+        "kernel_cycles": cycles,
+        "ta_busy_frac": c["TA_TA_BUSY_sum"] / 256 / cycles,
+        "td_busy_frac": c["TD_TD_BUSY_sum"] / 256 / cycles,
+        "l1_line_accesses_per_launch": c["TCP_TOTAL_CACHE_ACCESSES_sum"],
+        "l1_to_l2_read_requests_per_launch": c["TCP_TCC_READ_REQ_sum"],
+        "vector_load_wave_instructions_per_launch": c["TA_FLAT_READ_WAVEFRONTS_sum"],
+    }
 json.dump(out, open("profiles/r01_closest_hit_pmc.json", "w"), indent=1)
 print(json.dumps(out, indent=1))

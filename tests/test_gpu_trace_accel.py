@@ -15,7 +15,7 @@ from raytracer_amd.lbvh import LBVH  # noqa: E402
 DEV = "cuda:0"
 WIDE = np.dtype([("origin", "<f4", 3), ("exp", "i1", 3), ("imask", "u1"), ("childBase", "<u4"),
                  ("triBase", "<u4"), ("leafMask", "<u4"), ("counts", "<u4"), ("q", "u1", (6, 8)),
-                 ("spare", "<u4", 12)])
+                 ("off16", "<u2", 8), ("cnt16", "<u2", 8), ("spare", "<u4", 4)])
 TRI = np.dtype([("v0", "<f4", 3), ("fi", "<u4"), ("v1", "<f4", 3), ("parent", "<u4"), ("v2", "<f4", 3),
                 ("k", "<u4")])
 NODE = np.dtype([("lft", "<u4"), ("rht", "<u4"), ("box", "<f4", 6)])
@@ -63,11 +63,15 @@ def _check(bvh, pos, tri):
     faces = bvh.d_faces.cpu().numpy().view(np.uint32)
     assert np.array_equal(tris["fi"], faces[tris["k"]])
     long_run = (wide["leafMask"] & 0x100) != 0
+    huge = (wide["leafMask"] & 0x200) != 0
     nib = (wide["counts"][:, None] >> (4 * np.arange(8, dtype=np.uint32))[None, :]) & 0xF   # [W, 8]
-    cnt = np.where(long_run[:, None], 0, nib)
-    assert (np.where(long_run[:, None], True, (cnt > 0) == (((leaf_mask[:, None] >> np.arange(8)) & 1) > 0))).all()
-    tri_total = np.where(long_run, wide["counts"], cnt.sum(axis=1)).astype(np.int64)
+    cnt = np.where(long_run[:, None], wide["cnt16"].astype(np.int64), nib.astype(np.int64))
+    is_leaf = ((leaf_mask[:, None] >> np.arange(8)) & 1) > 0
+    assert ((cnt > 0) == is_leaf)[~huge].all()
+    assert (nib[long_run & ~huge].max(axis=1) == 15).all() if (long_run & ~huge).any() else True
+    tri_total = np.where(huge, wide["counts"], cnt.sum(axis=1)).astype(np.int64)
     off = np.cumsum(cnt, axis=1) - cnt
+    assert (off[long_run & ~huge] == wide["off16"][long_run & ~huge])[is_leaf[long_run & ~huge]].all()
     tranges = np.zeros(N + 1, np.int64)
     np.add.at(tranges, wide["triBase"][tri_total > 0], 1)
     np.add.at(tranges, (wide["triBase"] + tri_total)[tri_total > 0], -1)
@@ -94,7 +98,7 @@ def _check(bvh, pos, tri):
     org = wide["origin"].astype(np.float64)
     tri_min = np.minimum(np.minimum(tris["v0"], tris["v1"]), tris["v2"]).astype(np.float64)
     tri_max = np.maximum(np.maximum(tris["v0"], tris["v1"]), tris["v2"]).astype(np.float64)
-    short = ~long_run
+    short = ~huge
     for s in range(8):
         sel = np.nonzero(((leaf_mask >> s) & 1).astype(bool) & short)[0]
         if sel.size == 0:
