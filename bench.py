@@ -35,7 +35,9 @@ from raytracer_amd.lbvh import LBVH  # noqa: E402
 from raytracer_amd.ray_tracer import closest_hit  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak
-LBVH_BYTES_PER_TRI = 368  # algorithmic bytes of the build per triangle of a non-indexed soup
+# algorithmic bytes of the build per triangle of a non-indexed soup: bounds 36, Morton 52, sort 68, run
+# heads 8, leaf boxes 84, Karras links 16, refit 104
+LBVH_BYTES_PER_TRI = 368
 
 
 def parse():
