@@ -456,7 +456,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(5, 5)))
     Hit8 best;
     uint32_t nodeVisits = 0, triTests = 0;
     unsigned long long totNodes = 0, totTris = 0, totRays = 0;
-    unsigned long long dbgIters = 0, dbgVisitLanes = 0, dbgTriRuns = 0, dbgTriLanes = 0, dbgEmpty = 0, dbgEmptyLimit = 0;
+    unsigned long long dbgIters = 0, dbgVisitLanes = 0, dbgTriRuns = 0, dbgTriLanes = 0, dbgEmpty = 0, dbgEmptyLimit = 0, dbgUsedSlots = 0, dbgLeafOnly = 0;
 
     auto restart = [&]() {
         best.t = FloatMax;
@@ -571,6 +571,11 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(5, 5)))
                     ++nodeVisits;
                 bool anyNoLimit = false;
                 const Visit vis = visit_record<COUNT>(wideBytes, cur, ray, sg, limit, anyNoLimit);
+                if (COUNT) {
+                    dbgUsedSlots += __popc(vis.imask | vis.leafSlots);
+                    if (vis.imask == 0u)
+                        ++dbgLeafOnly;
+                }
                 if (COUNT && (vis.leafC | vis.inner) == 0u) {
                     ++dbgEmpty; // visits that found nothing
                     if (anyNoLimit)
@@ -633,10 +638,14 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(5, 5)))
         for (int o = 32; o > 0; o >>= 1) {
             dbgEmpty += __shfl_xor(dbgEmpty, o, 64);
             dbgEmptyLimit += __shfl_xor(dbgEmptyLimit, o, 64);
+            dbgUsedSlots += __shfl_xor(dbgUsedSlots, o, 64);
+            dbgLeafOnly += __shfl_xor(dbgLeafOnly, o, 64);
         }
         if (lane == 0) {
             atomicAdd(&counters[7], dbgEmpty);
             atomicAdd(&counters[8], dbgEmptyLimit);
+            atomicAdd(&counters[9], dbgUsedSlots);
+            atomicAdd(&counters[10], dbgLeafOnly);
         }
     }
 }

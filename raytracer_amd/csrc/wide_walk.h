@@ -254,6 +254,7 @@ struct Visit {
     uint32_t imask;        // all subtree slots of the record
     uint32_t childBase;    // wide node of the first subtree slot
     uint32_t leafW, leafC; // triangle records from the first to the last hit leaf slot (leafC == 0: none)
+    uint32_t leafSlots;    // all leaf slots of the record
 };
 
 // Slab tests of the eight slots of record `cur` against the ray, conservative: a slot is dropped only
@@ -314,6 +315,7 @@ __device__ __forceinline__ Visit visit_record(const char *__restrict__ wideBytes
     v.imask = r0.w >> 24;
     v.childBase = r1.x;
     v.inner = hits & v.imask;
+    v.leafSlots = r1.z & 0xffu;
     v.leafW = v.leafC = 0u;
     const uint32_t leafHits = hits & r1.z & 0xffu;
     if (leafHits != 0u) {

@@ -61,7 +61,8 @@ def closest_hit(lbvh: LBVH, rays, count: bool = False, out=None, layout: str = "
         return t, bary, prim, {"node_fetches": int(c[0]), "tri_tests": int(c[1]), "rays": int(c[2]),
                                "wave_passes": int(c[3]), "visit_lanes": int(c[4]), "tri_phases": int(c[5]),
                                "tri_lanes": int(c[6]), "empty_visits": int(c[7]),
-                               "empty_visits_by_limit": int(c[8])}
+                               "empty_visits_by_limit": int(c[8]), "used_slots_visited": int(c[9]),
+                               "leaf_only_visits": int(c[10])}
     return t, bary, prim
 
 
