@@ -42,6 +42,15 @@ struct HDDA3D {
         tSide = ((fl - pFlt + .5f) * toF3(sign) + .5f) * tDlt + tCurr;
         chPos = {static_cast<int>(fl.x), static_cast<int>(fl.y), static_cast<int>(fl.z)};
     }
+    // The same values with the ray's |1 / dir| at hand: voxPerChild is a power of two, so scaling by it
+    // (or by its reciprocal) rounds exactly as the divisions above do.
+    KK_D void Prepare(const Ray &ray, f3 absInvDir, f3 min, float voxPerChild) {
+        tDlt = absInvDir * voxPerChild;
+        const f3 pFlt = (ray.pos + tCurr * ray.dir - min) * (1.f / voxPerChild);
+        const f3 fl = vfloor(pFlt);
+        tSide = ((fl - pFlt + .5f) * toF3(sign) + .5f) * tDlt + tCurr;
+        chPos = {static_cast<int>(fl.x), static_cast<int>(fl.y), static_cast<int>(fl.z)};
+    }
     KK_D void Next() {
         mask.x = static_cast<int>((tSide.x < tSide.y) & (tSide.x <= tSide.z));
         mask.y = static_cast<int>((tSide.y < tSide.z) & (tSide.y <= tSide.x));
@@ -110,6 +119,48 @@ struct DepthDDA2D {
             tDlt2Dep = fabsf(ray.dir.z);
         }
         return (depSign.x | depSign.y | depSign.z) != 0;
+    }
+    // The same with the ray's direction signs and |1 / dir| at hand.
+    KK_D bool Init(float t_, float maxPosValInBrick, int minDepPos, int maxDepPos, f3 pib, i3 raySign,
+                   f3 absInvDir, const Ray &ray) {
+        dep = 0.f;
+        tDlt2Dep = 0.f;
+        sign = raySign;
+        mask = {0, 0, 0};
+        t = tStart = t_;
+        const f3 d = {sign.x == 0 ? INFINITY : sign.x > 0 ? pib.x : maxPosValInBrick - pib.x,
+                      sign.y == 0 ? INFINITY : sign.y > 0 ? pib.y : maxPosValInBrick - pib.y,
+                      sign.z == 0 ? INFINITY : sign.z > 0 ? pib.z : maxPosValInBrick - pib.z};
+        // the face the ray enters through, if it is within half a voxel of it
+        const int axis = d.x < d.y && d.x <= d.z ? 0 : d.y < d.z && d.y <= d.x ? 1 : d.z < d.x && d.z <= d.y ? 2 : -1;
+        if (axis < 0)
+            return false;
+        const float dAxis = axis == 0 ? d.x : axis == 1 ? d.y : d.z;
+        const int sAxis = axis == 0 ? sign.x : axis == 1 ? sign.y : sign.z;
+        if (sAxis == 0 || dAxis >= .5f)
+            return false;
+        tDlt = absInvDir;
+        const f3 fl = vfloor(pib);
+        posInBrick = {static_cast<int>(fl.x), static_cast<int>(fl.y), static_cast<int>(fl.z)};
+        tSide = ((fl - pib + .5f) * toF3(sign) + .5f) * tDlt + t;
+        const int depPos = sAxis == 1 ? minDepPos : maxDepPos;
+        if (axis == 0) {
+            posInBrick.x = depPos;
+            sign.x = 0;
+            tSide.x = INFINITY;
+            tDlt2Dep = fabsf(ray.dir.x);
+        } else if (axis == 1) {
+            posInBrick.y = depPos;
+            sign.y = 0;
+            tSide.y = INFINITY;
+            tDlt2Dep = fabsf(ray.dir.y);
+        } else {
+            posInBrick.z = depPos;
+            sign.z = 0;
+            tSide.z = INFINITY;
+            tDlt2Dep = fabsf(ray.dir.z);
+        }
+        return true;
     }
     KK_D void StepNext() {
         mask.x = static_cast<int>((tSide.x < tSide.y) & (tSide.x <= tSide.z));
@@ -290,161 +341,211 @@ __global__ __launch_bounds__(THREADS) void dvr_kernel(const kk_vdb_device_data v
             alive = !(tEnter >= tExit);
         }
         if (alive) {
-            // VDBStack, dda.h:13-33: two entries are enough for three levels
-            int lev = p.root_lev + 1;
-            float tExits[2] = {0.f, 0.f};
-            kk_vdb_node nodes[2];
-            nodes[0] = nodes[1] = nodePools[p.node_starts[p.root_lev]];
-            --lev;
-            tExits[lev - 1] = tExit - Eps;
+            // VDBStack, dda.h:13-33. With at most three levels a ray is either in the root's grid or in
+            // one level-1 node's grid, so the stack is the state of the grid being walked (kept in
+            // registers: extent, shift, child-pool row, exit distance) plus the root's, which every lane
+            // shares. `lev` above the root's means the walk is over.
+            const int rootLev = p.root_lev;
+            const int DONE = rootLev + 1;
+            // the per-level parameters are picked with selects: indexing kernel arguments with a
+            // run-time level makes the compiler split the byte offset over a scalar load's operands
+            const bool three = rootLev == 2;
+            const kk_vdb_node root = nodePools[three ? p.node_starts[2] : p.node_starts[1]];
+            const f3 rootMin = toF3(root.pos);
+            const uint32_t *rootChildren = childPools + (three ? p.child_starts[1] : p.child_starts[0]) +
+                                           root.child_pool_offs_relative;
+            const int rootDim = three ? p.dims[2] : p.dims[1];
+            const int rootL2 = three ? p.log2_dims[2] : p.log2_dims[1];
+            const float rootVox = three ? p.voxs_per_child[2] : p.voxs_per_child[1];
+            const float tExitRoot = tExit - Eps;
+            // grids below the root exist only in a three-level tree
+            const int subDim = p.dims[1], subL2 = p.log2_dims[1];
+            const float subVox = p.voxs_per_child[1];
+            const f3 absInvDir = vabs(1.f / eyeRay.dir);
+
+            int lev = rootLev;
+            int dimLev = rootDim, l2 = rootL2;
+            const uint32_t *children = rootChildren;
+            float tExitLev = tExitRoot;
 
             HDDA3D h;
             h.sign = {sgn(eyeRay.dir.x), sgn(eyeRay.dir.y), sgn(eyeRay.dir.z)};
             h.mask = {0, 0, 0};
             h.tCurr = tEnter + Eps;
             h.tNext = 0.f;
-            h.Prepare(eyeRay, F3(0.f), p.voxs_per_child[p.root_lev]);
+            h.Prepare(eyeRay, absInvDir, rootMin, rootVox);
 
             const float dims0f = p.voxs_per_child[1];
-            // every pass either steps the DDA or descends a level; the guard only bounds a walk fed with
-            // non-finite input
-            for (int guard = 0; guard < (1 << 20) && lev != p.root_lev + 1; ++guard) {
-                const int dimLev = p.dims[lev];
-                if (h.chPos.x < 0 || h.chPos.x >= dimLev || h.chPos.y < 0 || h.chPos.y >= dimLev ||
-                    h.chPos.z < 0 || h.chPos.z >= dimLev)
-                    break;
-                h.Next();
-                const kk_vdb_node &curr = nodes[lev - 1];
-                const int l2 = p.log2_dims[lev];
-                const uint32_t rel = (static_cast<uint32_t>(h.chPos.z) << (l2 << 1)) |
-                                     (static_cast<uint32_t>(h.chPos.y) << l2) |
-                                     static_cast<uint32_t>(h.chPos.x);
-                const uint32_t ch =
-                    childPools[p.child_starts[lev - 1] + curr.child_pool_offs_relative + rel];
-                if (ch != UndefRltIdx) {
-                    if (lev == 1) {
+#ifdef KK_DBG
+            if (x == 100 && y == 75) printf("start lev %d dim %d l2 %d ch %d %d %d tCurr %f tExit %f vox %f absInv %f %f %f\n", lev, dimLev, l2, h.chPos.x, h.chPos.y, h.chPos.z, h.tCurr, tExitLev, rootVox, absInvDir.x, absInvDir.y, absInvDir.z);
+#endif
+            // Pop, dda.h:28-32: leave every grid whose exit lies behind tCurr
+            auto ascend = [&]() {
+                if (h.tCurr >= tExitLev) {
+                    if (lev == rootLev)
+                        lev = DONE;
+                    else {
+                        lev = rootLev;
+                        dimLev = rootDim;
+                        l2 = rootL2;
+                        children = rootChildren;
+                        tExitLev = tExitRoot;
+                        h.Prepare(eyeRay, absInvDir, rootMin, rootVox);
+                        if (h.tCurr >= tExitRoot)
+                            lev = DONE;
+                    }
+                }
+            };
+
+            // A wave alternates between two phases so that its lanes do the same kind of work together:
+            // every lane steps its DDA until it stands in a leaf (or has left the tree), then the lanes
+            // in leaves skip and sample. Each pass of the inner loop steps the DDA or descends a level;
+            // the guard only bounds a walk fed with non-finite input.
+            uint32_t leafIdx = UndefRltIdx;
+            for (int guard = 0; guard < (1 << 20) && lev != DONE; ++guard) {
+                for (; guard < (1 << 20) && lev != DONE && leafIdx == UndefRltIdx; ++guard) {
+                    if (static_cast<uint32_t>(h.chPos.x) >= static_cast<uint32_t>(dimLev) ||
+                        static_cast<uint32_t>(h.chPos.y) >= static_cast<uint32_t>(dimLev) ||
+                        static_cast<uint32_t>(h.chPos.z) >= static_cast<uint32_t>(dimLev)) {
+                        lev = DONE;
+                        break;
+                    }
+                    h.Next();
+                    const uint32_t rel = (static_cast<uint32_t>(h.chPos.z) << (l2 << 1)) |
+                                         (static_cast<uint32_t>(h.chPos.y) << l2) |
+                                         static_cast<uint32_t>(h.chPos.x);
+                    const uint32_t ch = children[rel];
+#ifdef KK_DBG
+                    if (x == 100 && y == 75) printf("step lev %d dim %d l2 %d ch %d %d %d rel %u child %u tCurr %f tNext %f tExitLev %f\n", lev, dimLev, l2, h.chPos.x, h.chPos.y, h.chPos.z, rel, ch, h.tCurr, h.tNext, tExitLev);
+#endif
+                    if (ch == UndefRltIdx) {
+                        h.Step();
+                        ascend();
+                    } else if (lev == 1) {
+                        leafIdx = ch;
+                    } else {
+                        // Push, dda.h:23-27
+                        const kk_vdb_node sub = nodePools[p.node_starts[1] + ch];
+                        lev = 1;
+                        dimLev = subDim;
+                        l2 = subL2;
+                        children = childPools + p.child_starts[0] + sub.child_pool_offs_relative;
+                        tExitLev = h.tNext - Eps;
                         h.tCurr += Eps;
-                        InLeaf param{h.tCurr, h.tNext - Eps};
-                        const kk_vdb_node leaf = nodePools[p.node_starts[0] + ch];
-                        if (COUNT)
-                            ++nBricks;
-                        // ---- inLeafCallback, ray_caster_dpbx_vdb.cu:194-273 ----
-                        bool keepGoing = true;
-                        {
-                            param.tCurr = step * ceilf(param.tCurr / step);
-                            const f3 brickMinVoxPos = toF3(leaf.pos);
-                            f3 posInBrick = eyeRay.pos + param.tCurr * eyeRay.dir - brickMinVoxPos;
-                            const i3 origin = {leaf.brick_pos_in_atlas[0] * A,
-                                               leaf.brick_pos_in_atlas[1] * A,
-                                               leaf.brick_pos_in_atlas[2] * A};
-                            const f3 atlasBrickMinVoxPos = {
-                                static_cast<float>(origin.x + p.apron_dep_wid),
-                                static_cast<float>(origin.y + p.apron_dep_wid),
-                                static_cast<float>(origin.z + p.apron_dep_wid)};
-                            const T *__restrict__ brick = atlas + brickVox * ch;
-                            bool skipped = false;
-                            if (useDepthBox) {
-                                // depthSkip, :139-162
-                                DepthDDA2D d;
-                                if (d.Init(param.tCurr, dims0f, p.min_dep_pos_val_in_brick,
-                                           p.max_dep_pos_val_in_brick, posInBrick, eyeRay)) {
-                                    while (true) {
-                                        const int lx = d.posInBrick.x + p.apron_dep_wid;
-                                        const int ly = d.posInBrick.y + p.apron_dep_wid;
-                                        const int lz = d.posInBrick.z + p.apron_dep_wid;
-                                        T dep = 0; // outside the brick: border
-                                        if (lx >= 0 && lx < A && ly >= 0 && ly < A && lz >= 0 && lz < A)
-                                            dep = brick[(static_cast<size_t>(lz) * A + ly) * A + lx];
-                                        if (static_cast<float>(dep) <= d.dep)
-                                            break;
-                                        if (d.t >= param.tExit) {
-                                            skipped = true;
-                                            break;
-                                        }
-                                        param.tCurr = d.t;
-                                        d.StepNext();
+                        h.Prepare(eyeRay, absInvDir, toF3(sub.pos), subVox);
+                        ascend();
+                    }
+                }
+                if (lev == DONE || leafIdx == UndefRltIdx)
+                    break;
+
+                {
+                    const uint32_t ch = leafIdx;
+                    leafIdx = UndefRltIdx;
+                    h.tCurr += Eps;
+                    InLeaf param{h.tCurr, h.tNext - Eps};
+                    const kk_vdb_node leaf = nodePools[p.node_starts[0] + ch];
+                    if (COUNT)
+                        ++nBricks;
+                    // ---- inLeafCallback, ray_caster_dpbx_vdb.cu:194-273 ----
+                    bool keepGoing = true;
+                    {
+                        param.tCurr = step * ceilf(param.tCurr / step);
+                        const f3 brickMinVoxPos = toF3(leaf.pos);
+                        f3 posInBrick = eyeRay.pos + param.tCurr * eyeRay.dir - brickMinVoxPos;
+                        const i3 origin = {leaf.brick_pos_in_atlas[0] * A, leaf.brick_pos_in_atlas[1] * A,
+                                           leaf.brick_pos_in_atlas[2] * A};
+                        const f3 atlasBrickMinVoxPos = {static_cast<float>(origin.x + p.apron_dep_wid),
+                                                        static_cast<float>(origin.y + p.apron_dep_wid),
+                                                        static_cast<float>(origin.z + p.apron_dep_wid)};
+                        const T *__restrict__ brick = atlas + brickVox * ch;
+                        bool skipped = false;
+                        if (useDepthBox) {
+                            // depthSkip, :139-162
+                            DepthDDA2D d;
+                            if (d.Init(param.tCurr, dims0f, p.min_dep_pos_val_in_brick,
+                                       p.max_dep_pos_val_in_brick, posInBrick, h.sign, absInvDir, eyeRay)) {
+                                while (true) {
+                                    const int lx = d.posInBrick.x + p.apron_dep_wid;
+                                    const int ly = d.posInBrick.y + p.apron_dep_wid;
+                                    const int lz = d.posInBrick.z + p.apron_dep_wid;
+                                    T dep = 0; // outside the brick: border
+                                    if (lx >= 0 && lx < A && ly >= 0 && ly < A && lz >= 0 && lz < A)
+                                        dep = brick[(static_cast<size_t>(lz) * A + ly) * A + lx];
+                                    if (static_cast<float>(dep) <= d.dep)
+                                        break;
+                                    if (d.t >= param.tExit) {
+                                        skipped = true;
+                                        break;
                                     }
-                                }
-                                if (!skipped) {
-                                    param.tCurr = step * ceilf(param.tCurr / step);
-                                    posInBrick = eyeRay.pos + param.tCurr * eyeRay.dir - brickMinVoxPos;
+                                    param.tCurr = d.t;
+                                    d.StepNext();
                                 }
                             }
                             if (!skipped) {
-                                while (param.tCurr < param.tExit && !(posInBrick.x < 0.f) &&
-                                       !(posInBrick.x >= dims0f) && !(posInBrick.y < 0.f) &&
-                                       !(posInBrick.y >= dims0f) && !(posInBrick.z < 0.f) &&
-                                       !(posInBrick.z >= dims0f)) {
-                                    f3 samplePos = atlasBrickMinVoxPos + posInBrick;
-                                    const float scalar = sampleBrick<T>(brick, A, origin, samplePos, norm);
-                                    const f4 tfCol = tfLookup(s_tf, scalar);
-                                    f3 tfColRGB = {tfCol.x, tfCol.y, tfCol.z};
-                                    if (COUNT)
-                                        ++nSamples;
-                                    if (SHADING) {
-                                        f3 N;
-                                        samplePos.x += .5f;
-                                        float v0 = sampleBrick<T>(brick, A, origin, samplePos, norm);
-                                        samplePos.x -= 1.f;
-                                        float v1 = sampleBrick<T>(brick, A, origin, samplePos, norm);
-                                        N.x = v1 - v0;
-                                        samplePos.y += .5f;
-                                        v0 = sampleBrick<T>(brick, A, origin, samplePos, norm);
-                                        samplePos.y -= 1.f;
-                                        v1 = sampleBrick<T>(brick, A, origin, samplePos, norm);
-                                        N.y = v1 - v0;
-                                        samplePos.z += .5f;
-                                        v0 = sampleBrick<T>(brick, A, origin, samplePos, norm);
-                                        samplePos.z -= 1.f;
-                                        v1 = sampleBrick<T>(brick, A, origin, samplePos, norm);
-                                        N.z = v1 - v0;
-                                        N = normalize(N);
-                                        if (dot(eyeRay.dir, N) > 0.f)
-                                            N = -N;
-                                        const f3 lightPos = {rp.light_pos[0], rp.light_pos[1], rp.light_pos[2]};
-                                        const f3 lightCol = {rp.light_col[0], rp.light_col[1], rp.light_col[2]};
-                                        const f3 p2lDir = normalize(lightPos - brickMinVoxPos - posInBrick);
-                                        const f3 ambient = rp.ka * tfColRGB;
-                                        const f3 diffuse =
-                                            rp.kd * gmax(0.f, dot(N, p2lDir)) * tfColRGB * lightCol;
-                                        const f3 hfDir = normalize(p2lDir - eyeRay.dir);
-                                        const f3 specular =
-                                            rp.ks * powf(gmax(0.f, dot(N, hfDir)), rp.shiness) * lightCol;
-                                        tfColRGB = {ambient.x + diffuse.x + specular.x,
-                                                    ambient.y + diffuse.y + specular.y,
-                                                    ambient.z + diffuse.z + specular.z};
-                                    }
-                                    rgb = rgb + (1.f - a) * tfCol.w * tfColRGB;
-                                    a = a + (1.f - a) * tfCol.w;
-                                    if (a >= rp.max_alpha) {
-                                        keepGoing = false;
-                                        break;
-                                    }
-                                    param.tCurr += step;
-                                    posInBrick = posInBrick + dltPos;
-                                }
+                                param.tCurr = step * ceilf(param.tCurr / step);
+                                posInBrick = eyeRay.pos + param.tCurr * eyeRay.dir - brickMinVoxPos;
                             }
                         }
-                        if (!keepGoing)
-                            break;
-                        h.Step();
-                    } else {
-                        // Push, dda.h:23-27
-                        const float pushedExit = h.tNext - Eps;
-                        --lev;
-                        nodes[lev - 1] = nodePools[p.node_starts[lev] + ch];
-                        tExits[lev - 1] = pushedExit;
-                        h.tCurr += Eps;
-                        h.Prepare(eyeRay, toF3(nodes[lev - 1].pos), p.voxs_per_child[lev]);
+                        if (!skipped) {
+                            while (param.tCurr < param.tExit && !(posInBrick.x < 0.f) &&
+                                   !(posInBrick.x >= dims0f) && !(posInBrick.y < 0.f) &&
+                                   !(posInBrick.y >= dims0f) && !(posInBrick.z < 0.f) &&
+                                   !(posInBrick.z >= dims0f)) {
+                                f3 samplePos = atlasBrickMinVoxPos + posInBrick;
+                                const float scalar = sampleBrick<T>(brick, A, origin, samplePos, norm);
+                                const f4 tfCol = tfLookup(s_tf, scalar);
+                                f3 tfColRGB = {tfCol.x, tfCol.y, tfCol.z};
+                                if (COUNT)
+                                    ++nSamples;
+                                if (SHADING) {
+                                    f3 N;
+                                    samplePos.x += .5f;
+                                    float v0 = sampleBrick<T>(brick, A, origin, samplePos, norm);
+                                    samplePos.x -= 1.f;
+                                    float v1 = sampleBrick<T>(brick, A, origin, samplePos, norm);
+                                    N.x = v1 - v0;
+                                    samplePos.y += .5f;
+                                    v0 = sampleBrick<T>(brick, A, origin, samplePos, norm);
+                                    samplePos.y -= 1.f;
+                                    v1 = sampleBrick<T>(brick, A, origin, samplePos, norm);
+                                    N.y = v1 - v0;
+                                    samplePos.z += .5f;
+                                    v0 = sampleBrick<T>(brick, A, origin, samplePos, norm);
+                                    samplePos.z -= 1.f;
+                                    v1 = sampleBrick<T>(brick, A, origin, samplePos, norm);
+                                    N.z = v1 - v0;
+                                    N = normalize(N);
+                                    if (dot(eyeRay.dir, N) > 0.f)
+                                        N = -N;
+                                    const f3 lightPos = {rp.light_pos[0], rp.light_pos[1], rp.light_pos[2]};
+                                    const f3 lightCol = {rp.light_col[0], rp.light_col[1], rp.light_col[2]};
+                                    const f3 p2lDir = normalize(lightPos - brickMinVoxPos - posInBrick);
+                                    const f3 ambient = rp.ka * tfColRGB;
+                                    const f3 diffuse =
+                                        rp.kd * gmax(0.f, dot(N, p2lDir)) * tfColRGB * lightCol;
+                                    const f3 hfDir = normalize(p2lDir - eyeRay.dir);
+                                    const f3 specular =
+                                        rp.ks * powf(gmax(0.f, dot(N, hfDir)), rp.shiness) * lightCol;
+                                    tfColRGB = {ambient.x + diffuse.x + specular.x,
+                                                ambient.y + diffuse.y + specular.y,
+                                                ambient.z + diffuse.z + specular.z};
+                                }
+                                rgb = rgb + (1.f - a) * tfCol.w * tfColRGB;
+                                a = a + (1.f - a) * tfCol.w;
+                                if (a >= rp.max_alpha) {
+                                    keepGoing = false;
+                                    break;
+                                }
+                                param.tCurr += step;
+                                posInBrick = posInBrick + dltPos;
+                            }
+                        }
                     }
-                } else
-                    h.Step();
-
-                while (h.tCurr >= tExits[lev - 1]) {
-                    ++lev;
-                    if (lev == p.root_lev + 1)
+                    if (!keepGoing)
                         break;
-                    h.Prepare(eyeRay, toF3(nodes[lev - 1].pos), p.voxs_per_child[lev]);
+                    h.Step();
+                    ascend();
                 }
             }
         }
