@@ -19,6 +19,20 @@ namespace kk {
 namespace dvr {
 
 constexpr int THREADS = 256;
+#ifdef KK_DBG_STEPS
+// diagnostics build: per-wave tallies kept in registers, added to counters[2..] once at the end
+#define KK_WAVE_TICK(k)
+#define KK_CLK() (COUNT ? clock64() : 0ll)
+#define KK_CLK_ADD(k, t0)                                                                                \
+    do {                                                                                                 \
+        if (COUNT)                                                                                       \
+            dbg[k] += clock64() - (t0);                                                                  \
+    } while (0)
+#else
+#define KK_WAVE_TICK(k)
+#define KK_CLK() 0ll
+#define KK_CLK_ADD(k, t0)
+#endif
 constexpr float Eps = .01f; // include/ray_caster/dda.h:11
 constexpr uint32_t UndefRltIdx = 0xFFFFFFFFu;
 
@@ -209,9 +223,9 @@ KK_D float sampleBrick(const T *__restrict__ brick, int A, i3 origin, f3 sp, con
     int k = static_cast<int>(fl.z) - origin.z;
     // A ray inside a brick's [0, dims0) box with the apron around it never leaves [0, A-2]; the clamp
     // only guards the address against non-finite coordinates.
-    i = i < 0 ? 0 : (i > A - 2 ? A - 2 : i);
-    j = j < 0 ? 0 : (j > A - 2 ? A - 2 : j);
-    k = k < 0 ? 0 : (k > A - 2 ? A - 2 : k);
+    i = max(0, min(i, A - 2));
+    j = max(0, min(j, A - 2));
+    k = max(0, min(k, A - 2));
     const T *p = brick + (static_cast<size_t>(k) * A + j) * A + i;
     const int sy = A, sz = A * A;
     const float v000 = norm(p[0]), v001 = norm(p[1]);
@@ -263,6 +277,8 @@ __global__ __launch_bounds__(THREADS) void dvr_kernel(const kk_vdb_device_data v
     s_norm[tid] = static_cast<float>(tid) / 255.f;
     __syncthreads();
     const Norm<T> norm{s_norm};
+    [[maybe_unused]] long long dbg[16] = {}; // only [12..15] are used: registers
+    [[maybe_unused]] const long long clkKernel = KK_CLK();
 
     // 16 x 16 pixel block = 2 x 2 waves of 8 x 8 pixels
     const int lane = tid & 63, wave = tid >> 6;
@@ -376,9 +392,6 @@ __global__ __launch_bounds__(THREADS) void dvr_kernel(const kk_vdb_device_data v
             h.Prepare(eyeRay, absInvDir, rootMin, rootVox);
 
             const float dims0f = p.voxs_per_child[1];
-#ifdef KK_DBG
-            if (x == 100 && y == 75) printf("start lev %d dim %d l2 %d ch %d %d %d tCurr %f tExit %f vox %f absInv %f %f %f\n", lev, dimLev, l2, h.chPos.x, h.chPos.y, h.chPos.z, h.tCurr, tExitLev, rootVox, absInvDir.x, absInvDir.y, absInvDir.z);
-#endif
             // Pop, dda.h:28-32: leave every grid whose exit lies behind tCurr
             auto ascend = [&]() {
                 if (h.tCurr >= tExitLev) {
@@ -397,33 +410,65 @@ __global__ __launch_bounds__(THREADS) void dvr_kernel(const kk_vdb_device_data v
                 }
             };
 
-            // A wave alternates between two phases so that its lanes do the same kind of work together:
-            // every lane steps its DDA until it stands in a leaf (or has left the tree), then the lanes
-            // in leaves skip and sample. Each pass of the inner loop steps the DDA or descends a level;
-            // the guard only bounds a walk fed with non-finite input.
+            // A wave's lanes do the same kind of work together: every lane runs over empty cells until
+            // something happens to it (a child, the grid's end, the node's exit), the lanes deal with
+            // that, and only when each of them stands in a leaf or has left the tree do the lanes in
+            // leaves skip and sample. `budget` bounds a walk fed with non-finite input.
             uint32_t leafIdx = UndefRltIdx;
-            for (int guard = 0; guard < (1 << 20) && lev != DONE; ++guard) {
-                for (; guard < (1 << 20) && lev != DONE && leafIdx == UndefRltIdx; ++guard) {
-                    if (static_cast<uint32_t>(h.chPos.x) >= static_cast<uint32_t>(dimLev) ||
-                        static_cast<uint32_t>(h.chPos.y) >= static_cast<uint32_t>(dimLev) ||
-                        static_cast<uint32_t>(h.chPos.z) >= static_cast<uint32_t>(dimLev)) {
-                        lev = DONE;
-                        break;
-                    }
-                    h.Next();
-                    const uint32_t rel = (static_cast<uint32_t>(h.chPos.z) << (l2 << 1)) |
-                                         (static_cast<uint32_t>(h.chPos.y) << l2) |
-                                         static_cast<uint32_t>(h.chPos.x);
-                    const uint32_t ch = children[rel];
-#ifdef KK_DBG
-                    if (x == 100 && y == 75) printf("step lev %d dim %d l2 %d ch %d %d %d rel %u child %u tCurr %f tNext %f tExitLev %f\n", lev, dimLev, l2, h.chPos.x, h.chPos.y, h.chPos.z, rel, ch, h.tCurr, h.tNext, tExitLev);
-#endif
-                    if (ch == UndefRltIdx) {
+            int budget = 1 << 20;
+            while (lev != DONE) {
+                while (lev != DONE && leafIdx == UndefRltIdx) {
+                    // The child of the cell after this one is fetched while this cell's is awaited: its
+                    // position follows from the step the DDA would take. `cell` = index in the grid's
+                    // child block, or none outside the grid.
+                    auto cellOf = [&](i3 c) -> uint32_t {
+                        const bool in = static_cast<uint32_t>(c.x) < static_cast<uint32_t>(dimLev) &&
+                                        static_cast<uint32_t>(c.y) < static_cast<uint32_t>(dimLev) &&
+                                        static_cast<uint32_t>(c.z) < static_cast<uint32_t>(dimLev);
+                        const uint32_t rel = (static_cast<uint32_t>(c.z) << (l2 << 1)) |
+                                             (static_cast<uint32_t>(c.y) << l2) | static_cast<uint32_t>(c.x);
+                        return in ? rel : UndefRltIdx;
+                    };
+                    [[maybe_unused]] const long long clkRun = KK_CLK();
+                    uint32_t cell = cellOf(h.chPos);
+                    bool inGrid = cell != UndefRltIdx;
+                    uint32_t ch = children[inGrid ? cell : 0u];
+                    uint32_t chAhead = UndefRltIdx;
+                    // one cell: true when the run over empty cells ends here
+                    auto visit = [&](uint32_t &chHere, uint32_t &chNext) -> bool {
+                        if (!inGrid)
+                            return true;
+                        h.Next();
+                        KK_WAVE_TICK(2);
+                        const uint32_t nextCell = cellOf(i3{h.chPos.x + h.mask.x * h.sign.x,
+                                                            h.chPos.y + h.mask.y * h.sign.y,
+                                                            h.chPos.z + h.mask.z * h.sign.z});
+                        chNext = children[nextCell != UndefRltIdx ? nextCell : 0u];
+                        if (chHere != UndefRltIdx)
+                            return true;
                         h.Step();
+                        if (h.tCurr >= tExitLev || --budget < 0)
+                            return true; // the node's exit comes before the grid's end
+                        inGrid = nextCell != UndefRltIdx;
+                        return false;
+                    };
+                    for (;;) {
+                        if (visit(ch, chAhead))
+                            break;
+                        if (visit(chAhead, ch)) {
+                            ch = chAhead;
+                            break;
+                        }
+                    }
+                    KK_CLK_ADD(13, clkRun);
+                    KK_WAVE_TICK(4);
+                    if (!inGrid || budget < 0)
+                        lev = DONE;
+                    else if (ch == UndefRltIdx)
                         ascend();
-                    } else if (lev == 1) {
+                    else if (lev == 1)
                         leafIdx = ch;
-                    } else {
+                    else {
                         // Push, dda.h:23-27
                         const kk_vdb_node sub = nodePools[p.node_starts[1] + ch];
                         lev = 1;
@@ -436,12 +481,17 @@ __global__ __launch_bounds__(THREADS) void dvr_kernel(const kk_vdb_device_data v
                         ascend();
                     }
                 }
-                if (lev == DONE || leafIdx == UndefRltIdx)
+                if (lev == DONE)
                     break;
 
                 {
                     const uint32_t ch = leafIdx;
                     leafIdx = UndefRltIdx;
+                    if (--budget < 0)
+                        break;
+                    KK_WAVE_TICK(6);
+                    [[maybe_unused]] const long long clkLeaf = KK_CLK();
+                    [[maybe_unused]] long long clkSample = 0;
                     h.tCurr += Eps;
                     InLeaf param{h.tCurr, h.tNext - Eps};
                     const kk_vdb_node leaf = nodePools[p.node_starts[0] + ch];
@@ -480,6 +530,7 @@ __global__ __launch_bounds__(THREADS) void dvr_kernel(const kk_vdb_device_data v
                                     }
                                     param.tCurr = d.t;
                                     d.StepNext();
+                                    KK_WAVE_TICK(8);
                                 }
                             }
                             if (!skipped) {
@@ -487,15 +538,18 @@ __global__ __launch_bounds__(THREADS) void dvr_kernel(const kk_vdb_device_data v
                                 posInBrick = eyeRay.pos + param.tCurr * eyeRay.dir - brickMinVoxPos;
                             }
                         }
+                        clkSample = KK_CLK();
                         if (!skipped) {
-                            while (param.tCurr < param.tExit && !(posInBrick.x < 0.f) &&
-                                   !(posInBrick.x >= dims0f) && !(posInBrick.y < 0.f) &&
-                                   !(posInBrick.y >= dims0f) && !(posInBrick.z < 0.f) &&
+                            // one test per pass: the conjunction is evaluated whole, not term by term
+                            while ((param.tCurr < param.tExit) & !(posInBrick.x < 0.f) &
+                                   !(posInBrick.x >= dims0f) & !(posInBrick.y < 0.f) &
+                                   !(posInBrick.y >= dims0f) & !(posInBrick.z < 0.f) &
                                    !(posInBrick.z >= dims0f)) {
                                 f3 samplePos = atlasBrickMinVoxPos + posInBrick;
                                 const float scalar = sampleBrick<T>(brick, A, origin, samplePos, norm);
                                 const f4 tfCol = tfLookup(s_tf, scalar);
                                 f3 tfColRGB = {tfCol.x, tfCol.y, tfCol.z};
+                                KK_WAVE_TICK(10);
                                 if (COUNT)
                                     ++nSamples;
                                 if (SHADING) {
@@ -542,6 +596,8 @@ __global__ __launch_bounds__(THREADS) void dvr_kernel(const kk_vdb_device_data v
                             }
                         }
                     }
+                    KK_CLK_ADD(14, clkSample);
+                    KK_CLK_ADD(15, clkLeaf);
                     if (!keepGoing)
                         break;
                     h.Step();
@@ -551,18 +607,37 @@ __global__ __launch_bounds__(THREADS) void dvr_kernel(const kk_vdb_device_data v
         }
 
         // HDRToLDRCorrect + GammaCorrect (include/cg/math.h:75-93), RGBA8 with alpha = opacity
-        rgb = rgb / (rgb + 1.f);
-        rgb.x = powf(rgb.x, 1.f / 2.2f);
-        rgb.y = powf(rgb.y, 1.f / 2.2f);
-        rgb.z = powf(rgb.z, 1.f / 2.2f);
-        uchar4 o;
-        o.x = static_cast<uint8_t>(255.f * rgb.x);
-        o.y = static_cast<uint8_t>(255.f * rgb.y);
-        o.z = static_cast<uint8_t>(255.f * rgb.z);
-        o.w = static_cast<uint8_t>(255.f * a);
+        // a pixel that gathered no opacity is black: the curve maps 0 to 0
+        uchar4 o = make_uchar4(0, 0, 0, 0);
+        if (a > 0.f) {
+            rgb = rgb / (rgb + 1.f);
+            rgb.x = powf(rgb.x, 1.f / 2.2f);
+            rgb.y = powf(rgb.y, 1.f / 2.2f);
+            rgb.z = powf(rgb.z, 1.f / 2.2f);
+            o.x = static_cast<uint8_t>(255.f * rgb.x);
+            o.y = static_cast<uint8_t>(255.f * rgb.y);
+            o.z = static_cast<uint8_t>(255.f * rgb.z);
+            o.w = static_cast<uint8_t>(255.f * a);
+        }
         reinterpret_cast<uchar4 *>(rgba)[static_cast<size_t>(y) * W + x] = o;
     }
 
+    KK_CLK_ADD(12, clkKernel);
+#ifdef KK_DBG_STEPS
+    if (COUNT) {
+        // tallies are per lane; every lane that was active at a tick holds the same count only if it
+        // was active at all of them, so take each tally's maximum over the wave
+        for (int k = 12; k < 16; ++k) {
+            long long v = dbg[k];
+            for (int o = 32; o > 0; o >>= 1) {
+                const long long w = __shfl_xor(v, o, 64);
+                v = w > v ? w : v;
+            }
+            if ((threadIdx.x & 63) == 0)
+                atomicAdd(&counters[k], static_cast<unsigned long long>(v));
+        }
+    }
+#endif
     if (COUNT) {
         for (int o = 32; o > 0; o >>= 1) {
             nSamples += __shfl_xor(nSamples, o, 64);
