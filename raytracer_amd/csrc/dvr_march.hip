@@ -19,20 +19,6 @@ namespace kk {
 namespace dvr {
 
 constexpr int THREADS = 256;
-#ifdef KK_DBG_STEPS
-// diagnostics build: per-wave tallies kept in registers, added to counters[2..] once at the end
-#define KK_WAVE_TICK(k)
-#define KK_CLK() (COUNT ? clock64() : 0ll)
-#define KK_CLK_ADD(k, t0)                                                                                \
-    do {                                                                                                 \
-        if (COUNT)                                                                                       \
-            dbg[k] += clock64() - (t0);                                                                  \
-    } while (0)
-#else
-#define KK_WAVE_TICK(k)
-#define KK_CLK() 0ll
-#define KK_CLK_ADD(k, t0)
-#endif
 constexpr float Eps = .01f; // include/ray_caster/dda.h:11
 constexpr uint32_t UndefRltIdx = 0xFFFFFFFFu;
 
@@ -60,7 +46,9 @@ struct HDDA3D {
     // (or by its reciprocal) rounds exactly as the divisions above do.
     KK_D void Prepare(const Ray &ray, f3 absInvDir, f3 min, float voxPerChild) {
         tDlt = absInvDir * voxPerChild;
-        const f3 pFlt = (ray.pos + tCurr * ray.dir - min) * (1.f / voxPerChild);
+        // 1 / 2^k, exact: the exponent field mirrored about the bias
+        const float invVox = __int_as_float(0x7F000000 - __float_as_int(voxPerChild));
+        const f3 pFlt = (ray.pos + tCurr * ray.dir - min) * invVox;
         const f3 fl = vfloor(pFlt);
         tSide = ((fl - pFlt + .5f) * toF3(sign) + .5f) * tDlt + tCurr;
         chPos = {static_cast<int>(fl.x), static_cast<int>(fl.y), static_cast<int>(fl.z)};
@@ -226,7 +214,10 @@ KK_D float sampleBrick(const T *__restrict__ brick, int A, i3 origin, f3 sp, con
     i = max(0, min(i, A - 2));
     j = max(0, min(j, A - 2));
     k = max(0, min(k, A - 2));
-    const T *p = brick + (static_cast<size_t>(k) * A + j) * A + i;
+    // offsets inside a brick fit 32 bits
+    const T *p = brick + (static_cast<uint32_t>(k) * static_cast<uint32_t>(A) + static_cast<uint32_t>(j)) *
+                             static_cast<uint32_t>(A) +
+                 static_cast<uint32_t>(i);
     const int sy = A, sz = A * A;
     const float v000 = norm(p[0]), v001 = norm(p[1]);
     const float v010 = norm(p[sy]), v011 = norm(p[sy + 1]);
@@ -277,8 +268,6 @@ __global__ __launch_bounds__(THREADS) void dvr_kernel(const kk_vdb_device_data v
     s_norm[tid] = static_cast<float>(tid) / 255.f;
     __syncthreads();
     const Norm<T> norm{s_norm};
-    [[maybe_unused]] long long dbg[16] = {}; // only [12..15] are used: registers
-    [[maybe_unused]] const long long clkKernel = KK_CLK();
 
     // 16 x 16 pixel block = 2 x 2 waves of 8 x 8 pixels
     const int lane = tid & 63, wave = tid >> 6;
@@ -429,7 +418,6 @@ __global__ __launch_bounds__(THREADS) void dvr_kernel(const kk_vdb_device_data v
                                              (static_cast<uint32_t>(c.y) << l2) | static_cast<uint32_t>(c.x);
                         return in ? rel : UndefRltIdx;
                     };
-                    [[maybe_unused]] const long long clkRun = KK_CLK();
                     uint32_t cell = cellOf(h.chPos);
                     bool inGrid = cell != UndefRltIdx;
                     uint32_t ch = children[inGrid ? cell : 0u];
@@ -439,7 +427,6 @@ __global__ __launch_bounds__(THREADS) void dvr_kernel(const kk_vdb_device_data v
                         if (!inGrid)
                             return true;
                         h.Next();
-                        KK_WAVE_TICK(2);
                         const uint32_t nextCell = cellOf(i3{h.chPos.x + h.mask.x * h.sign.x,
                                                             h.chPos.y + h.mask.y * h.sign.y,
                                                             h.chPos.z + h.mask.z * h.sign.z});
@@ -460,8 +447,6 @@ __global__ __launch_bounds__(THREADS) void dvr_kernel(const kk_vdb_device_data v
                             break;
                         }
                     }
-                    KK_CLK_ADD(13, clkRun);
-                    KK_WAVE_TICK(4);
                     if (!inGrid || budget < 0)
                         lev = DONE;
                     else if (ch == UndefRltIdx)
@@ -489,9 +474,6 @@ __global__ __launch_bounds__(THREADS) void dvr_kernel(const kk_vdb_device_data v
                     leafIdx = UndefRltIdx;
                     if (--budget < 0)
                         break;
-                    KK_WAVE_TICK(6);
-                    [[maybe_unused]] const long long clkLeaf = KK_CLK();
-                    [[maybe_unused]] long long clkSample = 0;
                     h.tCurr += Eps;
                     InLeaf param{h.tCurr, h.tNext - Eps};
                     const kk_vdb_node leaf = nodePools[p.node_starts[0] + ch];
@@ -521,7 +503,10 @@ __global__ __launch_bounds__(THREADS) void dvr_kernel(const kk_vdb_device_data v
                                     const int lz = d.posInBrick.z + p.apron_dep_wid;
                                     T dep = 0; // outside the brick: border
                                     if (lx >= 0 && lx < A && ly >= 0 && ly < A && lz >= 0 && lz < A)
-                                        dep = brick[(static_cast<size_t>(lz) * A + ly) * A + lx];
+                                        dep = brick[(static_cast<uint32_t>(lz) * static_cast<uint32_t>(A) +
+                                                     static_cast<uint32_t>(ly)) *
+                                                        static_cast<uint32_t>(A) +
+                                                    static_cast<uint32_t>(lx)];
                                     if (static_cast<float>(dep) <= d.dep)
                                         break;
                                     if (d.t >= param.tExit) {
@@ -530,7 +515,6 @@ __global__ __launch_bounds__(THREADS) void dvr_kernel(const kk_vdb_device_data v
                                     }
                                     param.tCurr = d.t;
                                     d.StepNext();
-                                    KK_WAVE_TICK(8);
                                 }
                             }
                             if (!skipped) {
@@ -538,7 +522,6 @@ __global__ __launch_bounds__(THREADS) void dvr_kernel(const kk_vdb_device_data v
                                 posInBrick = eyeRay.pos + param.tCurr * eyeRay.dir - brickMinVoxPos;
                             }
                         }
-                        clkSample = KK_CLK();
                         if (!skipped) {
                             // one test per pass: the conjunction is evaluated whole, not term by term
                             while ((param.tCurr < param.tExit) & !(posInBrick.x < 0.f) &
@@ -549,7 +532,6 @@ __global__ __launch_bounds__(THREADS) void dvr_kernel(const kk_vdb_device_data v
                                 const float scalar = sampleBrick<T>(brick, A, origin, samplePos, norm);
                                 const f4 tfCol = tfLookup(s_tf, scalar);
                                 f3 tfColRGB = {tfCol.x, tfCol.y, tfCol.z};
-                                KK_WAVE_TICK(10);
                                 if (COUNT)
                                     ++nSamples;
                                 if (SHADING) {
@@ -596,8 +578,6 @@ __global__ __launch_bounds__(THREADS) void dvr_kernel(const kk_vdb_device_data v
                             }
                         }
                     }
-                    KK_CLK_ADD(14, clkSample);
-                    KK_CLK_ADD(15, clkLeaf);
                     if (!keepGoing)
                         break;
                     h.Step();
@@ -622,22 +602,6 @@ __global__ __launch_bounds__(THREADS) void dvr_kernel(const kk_vdb_device_data v
         reinterpret_cast<uchar4 *>(rgba)[static_cast<size_t>(y) * W + x] = o;
     }
 
-    KK_CLK_ADD(12, clkKernel);
-#ifdef KK_DBG_STEPS
-    if (COUNT) {
-        // tallies are per lane; every lane that was active at a tick holds the same count only if it
-        // was active at all of them, so take each tally's maximum over the wave
-        for (int k = 12; k < 16; ++k) {
-            long long v = dbg[k];
-            for (int o = 32; o > 0; o >>= 1) {
-                const long long w = __shfl_xor(v, o, 64);
-                v = w > v ? w : v;
-            }
-            if ((threadIdx.x & 63) == 0)
-                atomicAdd(&counters[k], static_cast<unsigned long long>(v));
-        }
-    }
-#endif
     if (COUNT) {
         for (int o = 32; o > 0; o >>= 1) {
             nSamples += __shfl_xor(nSamples, o, 64);
@@ -1074,6 +1038,13 @@ int launch(const kk_vdb_device_data *h_vdb, const float *d_tf, const kk_dvr_para
     KK_REQUIRE(h_vdb->vdb_param.root_lev >= 1 && h_vdb->vdb_param.root_lev <= 2, "root level out of range");
     KK_REQUIRE(width > 0 && height > 0 && y0 >= 0 && y1 <= height && y0 <= y1, "bad image size or rows");
     KK_REQUIRE(stripeStride >= 1 && stripeFirst >= 0, "bad stripe selection");
+    for (int lev = 1; lev <= h_vdb->vdb_param.root_lev; ++lev) {
+        // the marcher scales by these instead of dividing, which is exact for powers of two only
+        int e = 0;
+        const float v = h_vdb->vdb_param.voxs_per_child[lev];
+        KK_REQUIRE(v >= 1.f && v <= 1073741824.f && frexpf(v, &e) == .5f,
+                   "voxels per child must be a power of two");
+    }
     const int stripes = static_cast<int>(div_up(y1 - y0, 16));
     if (y0 == y1 || stripeFirst >= stripes)
         return KK_OK;

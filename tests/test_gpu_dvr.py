@@ -120,6 +120,19 @@ def test_render_head_shape(oracle, orbit, eye_scale):
     _check_images(got, want)
 
 
+def test_render_axis_aligned_rays(oracle):
+    """Odd image sizes with the unrotated camera: the centre column's rays have dir.x == 0 exactly, the
+    centre row's dir.y == 0, the centre pixel's both, so the DDAs run with infinite step lengths."""
+    dim = (64, 128, 128)
+    vol = syn.head_volume(dim)
+    vdb, ref = _build_both(oracle, vol, (3, 2, 2), HEAD_TF.empty_scalar_ranges)
+    assert vdb.plan.param.root_lev == 2
+    got, want, ns_gpu, ns_cpu, *_ = _render_both(oracle, vdb, ref, HEAD_TF, dim, (2, 1, 1), 201, 151)
+    assert ns_gpu == ns_cpu and ns_cpu > 10_000
+    _check_images(got, want)
+    assert got[75, 100, 3] > 0  # the centre pixel's ray went through the head
+
+
 def test_render_three_levels_uint16_and_no_depth_box(oracle):
     vol = blob_volume((50, 33, 70), seed=5, dtype=np.uint16)
     top = 65535
