@@ -250,6 +250,12 @@ KK_D f4 tfLookup(const float4 *__restrict__ s_tf, float u) {
     return f4{t0.x, t0.y, t0.z, t0.w} * (1.f - a) + f4{t1.x, t1.y, t1.z, t1.w} * a;
 }
 
+// Element `i` of a three-entry kernel-argument array, picked with selects. A run-time index that is the
+// same for the whole wave makes the compiler read the element with a scalar load whose byte offset it
+// may split over the base and offset operands; the hardware drops the low two bits of each, so the load
+// can return a neighbouring element.
+template <typename V> KK_D V pick3(const V (&a)[3], int i) { return i == 0 ? a[0] : i == 1 ? a[1] : a[2]; }
+
 struct InLeaf {
     float tCurr, tExit;
 };
@@ -886,14 +892,14 @@ __global__ __launch_bounds__(THREADS) void vdb_target_kernel(const kk_vdb_device
         int lev = p.root_lev;
         float tExits[2] = {0.f, 0.f};
         kk_vdb_node nodes[2];
-        nodes[0] = nodes[1] = vdb.node_pools[p.node_starts[p.root_lev]];
+        nodes[0] = nodes[1] = vdb.node_pools[pick3(p.node_starts, p.root_lev)];
         tExits[lev - 1] = tExit - Eps;
         HDDA3D h;
         h.sign = {sgn(ray.dir.x), sgn(ray.dir.y), sgn(ray.dir.z)};
         h.mask = {0, 0, 0};
         h.tCurr = tEnter + Eps;
         h.tNext = 0.f;
-        h.Prepare(ray, F3(0.f), p.voxs_per_child[p.root_lev]);
+        h.Prepare(ray, F3(0.f), pick3(p.voxs_per_child, p.root_lev));
         if (target == KK_VDB_TARGET_AABBS && lev == displayLev)
             blend((ray.pos + h.tCurr * ray.dir - toF3(nodes[lev - 1].pos)) / p.vox_per_vdb);
 
