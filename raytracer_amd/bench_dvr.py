@@ -125,6 +125,7 @@ def run(dev: str, world: int, rank: int, dist=None, frames: int = 120, warmup: i
         torch.cuda.synchronize()
         ns, nb = int(counters[0]), int(counters[1])
         kernel_ms = ev0.elapsed_time(ev1) / frames
+        out["gpu_ms_per_frame"] = round(kernel_ms, 4)  # device-side time between the first and the last frame
         # 8 voxel bytes + 2 table entries (32 B, LDS) per sample from cache; compulsory HBM traffic is
         # the distinct bricks touched plus the 4 B per pixel written
         out.update({"samples_per_frame": ns, "brick_entries_per_frame": nb,
