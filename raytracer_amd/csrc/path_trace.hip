@@ -267,7 +267,7 @@ KK_D f3 renderScene(const Tracer &tracer, const kk_pt_scene &p, Rng &rng, Ray ra
 }
 
 template <bool WIDE>
-__global__ __launch_bounds__(THREADS) void path_trace_kernel(
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(5, 5))) void path_trace_kernel(
     const kk_lbvh_device_data *__restrict__ lbvh, const accel::View view, const kk_pt_scene p,
     const kk_pt_frame f, float *__restrict__ accum, uint8_t *__restrict__ rgba, int W, int H, int y0, int y1,
     float sampleIdx, uint32_t seed) {

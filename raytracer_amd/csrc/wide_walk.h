@@ -374,17 +374,18 @@ struct LaneStack {
     int stride;
 };
 
+// The overflow entries are an array of their own (`deep`, LANE_DEPTH - LANE_LDS_DEPTH entries in the
+// caller's private memory), so that the three words of the walk stay in registers.
 struct LaneWalk {
     uint32_t grpBase, grpBits;
     int sp;
-    uint2 deep[LANE_DEPTH - LANE_LDS_DEPTH];
     __device__ __forceinline__ void start(uint32_t oct) {
         sp = 0;
         grpBase = 0u;
         grpBits = (1u << (0u ^ oct)) | (1u << 8); // the root: slot 0 of a node whose only subtree is slot 0
     }
     // next record to visit; false when the walk is over
-    __device__ __forceinline__ bool next(const LaneStack &st, uint32_t oct, uint32_t &cur) {
+    __device__ __forceinline__ bool next(const LaneStack &st, const uint2 *deep, uint32_t oct, uint32_t &cur) {
         if ((grpBits & 0xffu) == 0u) {
             if (sp == 0)
                 return false;
@@ -403,7 +404,7 @@ struct LaneWalk {
         return true;
     }
     // the subtree hits of a visit become the current group; the rest of the old one waits
-    __device__ __forceinline__ void enter(const LaneStack &st, const Visit &v, uint32_t oct) {
+    __device__ __forceinline__ void enter(const LaneStack &st, uint2 *deep, const Visit &v, uint32_t oct) {
         if (v.inner == 0u)
             return;
         if ((grpBits & 0xffu) != 0u) {
@@ -442,17 +443,32 @@ __device__ __forceinline__ Hit8 closest_hit_lane(const View &v, Ray r, const Lan
     uint32_t unused = 0;
     bool unusedFlag = false;
     LaneWalk w;
+    uint2 deep[LANE_DEPTH - LANE_LDS_DEPTH];
     while (true) { // a second walk only when the final hit of the first fails its parent-box test
         best.t = FloatMax;
         best.bx = best.by = 0.f;
         best.fi = best.k = best.w = 0xFFFFFFFFu;
         w.start(sg.oct);
-        uint32_t cur;
-        while (w.next(st, sg.oct, cur)) {
-            const float limit = best.t + trav::CULL_SLACK * best.t;
-            const Visit vis = visit_record<false>(wideBytes, cur, ray, sg, limit, unusedFlag);
-            test_run<false, false>(v.recs, nodes, v.parents, ray, mode, vis.leafW, vis.leafC, best, unused);
-            w.enter(st, vis, sg.oct);
+        // Each pass of the loop a lane either visits a record or, while the last visit's triangles
+        // last, tests one of them: the lanes of a wave that test triangles do not hold up the ones that
+        // walk for the whole run. The order of a lane's own visits and tests is the plain one.
+        uint32_t pendW = 0u, pendC = 0u;
+        while (true) {
+            if (pendC == 0u) {
+                uint32_t cur;
+                if (!w.next(st, deep, sg.oct, cur))
+                    break;
+                const float limit = best.t + trav::CULL_SLACK * best.t;
+                const Visit vis = visit_record<false>(wideBytes, cur, ray, sg, limit, unusedFlag);
+                pendW = vis.leafW;
+                pendC = vis.leafC;
+                w.enter(st, deep, vis, sg.oct);
+            }
+            if (pendC != 0u) {
+                test_run<false, false>(v.recs, nodes, v.parents, ray, mode, pendW, 1u, best, unused);
+                ++pendW;
+                --pendC;
+            }
         }
         if (best.fi != 0xFFFFFFFFu && mode == MODE_FAST && !best.sure &&
             !passes_parent(nodes, v.recs[best.w].parent, ray)) {
@@ -482,12 +498,22 @@ __device__ __forceinline__ bool occluded_lane(const View &v, Ray r, float tMax, 
     const float limit = tMax + trav::CULL_SLACK * tMax;
     bool unusedFlag = false;
     LaneWalk w;
+    uint2 deep[LANE_DEPTH - LANE_LDS_DEPTH];
     w.start(sg.oct);
-    uint32_t cur;
-    while (w.next(st, sg.oct, cur)) {
-        const Visit vis = visit_record<false>(wideBytes, cur, ray, sg, limit, unusedFlag);
-        for (uint32_t t3 = vis.leafW; t3 < vis.leafW + vis.leafC; ++t3) {
-            const uint4 *p = reinterpret_cast<const uint4 *>(v.recs + t3);
+    // one record or one triangle per pass, as in closest_hit_lane
+    uint32_t pendW = 0u, pendC = 0u;
+    while (true) {
+        if (pendC == 0u) {
+            uint32_t cur;
+            if (!w.next(st, deep, sg.oct, cur))
+                return false;
+            const Visit vis = visit_record<false>(wideBytes, cur, ray, sg, limit, unusedFlag);
+            pendW = vis.leafW;
+            pendC = vis.leafC;
+            w.enter(st, deep, vis, sg.oct);
+        }
+        if (pendC != 0u) {
+            const uint4 *p = reinterpret_cast<const uint4 *>(v.recs + pendW);
             const uint4 a = p[0], b = p[1], c = p[2];
             float bx, by;
             const float t = HitTriangle(r, F3(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z)),
@@ -496,10 +522,10 @@ __device__ __forceinline__ bool occluded_lane(const View &v, Ray r, float tMax, 
             if (t >= 0.f && t < tMax &&
                 (mode == MODE_CHAIN ? passes_chain(nodes, v.parents, b.w, ray) : passes_parent(nodes, b.w, ray)))
                 return true;
+            ++pendW;
+            --pendC;
         }
-        w.enter(st, vis, sg.oct);
     }
-    return false;
 }
 
 } // namespace accel
