@@ -50,6 +50,7 @@ class LBVH : Noncopyable {
     HIP::DeviceBuffer<float> d_positions;
     HIP::DeviceBuffer<IndexTy> d_facePositionIndices;
     HIP::DeviceBuffer<uint8_t> d_workspace;
+    size_t leafAABBsOffs = 0; // of the per-leaf boxes inside d_workspace
     HIP::DeviceBuffer<DeviceData> d_deviceDat;
     DeviceData deviceDat{};
 
@@ -97,6 +98,7 @@ class LBVH : Noncopyable {
         }
         std::cout << StatTag << " Builded LBVH.\n\tcompact num: " << deviceDat.compactedFaceNum
                   << ", face num: " << deviceDat.faceNum << "\n";
+        leafAABBsOffs = lay.leaf_aabbs;
         isComplete = true;
         if (!logPath.empty())
             writeLog(inputMesh, logPath);
@@ -109,6 +111,10 @@ class LBVH : Noncopyable {
     // Device copies of the mesh arrays the tree indexes; the renderer shares them.
     const float *GetDevicePositions() const { return d_positions.data(); }
     const IndexTy *GetDeviceFacePositionIndices() const { return d_facePositionIndices.data(); }
+    // float[compactedFaceNum][6]: the boxes of the leaves, left in the workspace by the build.
+    const float *GetDeviceLeafAABBs() const {
+        return isComplete ? reinterpret_cast<const float *>(d_workspace.data() + leafAABBsOffs) : nullptr;
+    }
 
   private:
     void clear() {

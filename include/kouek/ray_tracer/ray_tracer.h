@@ -116,7 +116,7 @@ class RayTracer : Noncopyable {
         scene.light_tot_area = tot;
         modified = true;
     }
-    // Also builds the trace-side tree of `lbvh` (kk_trace_accel_build); the image is the same with
+    // Also builds the trace-side tree of `lbvh` (kk_trace_accel_build_with_leaf_boxes); the image is the same with
     // and without it, it only makes the hits cheaper to find.
     void SetLBVH(std::shared_ptr<LBVH> lbvh) {
         this->lbvh = lbvh;
@@ -128,11 +128,11 @@ class RayTracer : Noncopyable {
         if (!d_traceTree.resize(bytes))
             return;
         if (!KOUEK_HIP_CHECK(ErrTag.data(),
-                             kk_trace_accel_build(reinterpret_cast<const kk_lbvh_device_data *>(
-                                                      lbvh->GetDeivceDataDevicePtr()),
-                                                  lbvh->GetDevicePositions(),
-                                                  lbvh->GetDeviceFacePositionIndices(), dd.faceNum,
-                                                  dd.compactedFaceNum, d_traceTree.data(), bytes, nullptr)))
+                             kk_trace_accel_build_with_leaf_boxes(
+                                 reinterpret_cast<const kk_lbvh_device_data *>(lbvh->GetDeivceDataDevicePtr()),
+                                 lbvh->GetDevicePositions(), lbvh->GetDeviceFacePositionIndices(), dd.faceNum,
+                                 dd.compactedFaceNum, lbvh->GetDeviceLeafAABBs(), d_traceTree.data(), bytes,
+                                 nullptr)))
             return;
         scene.trace_accel = d_traceTree.data();
         scene.accel_face_num = dd.faceNum;

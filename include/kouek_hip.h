@@ -178,6 +178,13 @@ int kk_trace_accel_layout(uint32_t face_num, uint32_t compacted_face_num, kk_tra
 int kk_trace_accel_build(const kk_lbvh_device_data *d_lbvh, const float *d_positions,
                          const uint32_t *d_face_pos_idx, uint32_t face_num,
                          uint32_t compacted_face_num, void *d_accel, size_t accel_bytes, void *stream);
+/* The same with the per-leaf boxes the LBVH build left in its workspace (d_leaf_aabbs float[M][6] at
+ * kk_lbvh_workspace_layout().leaf_aabbs, valid until that workspace is reused): saves the pass that
+ * gathers the vertices of every leaf again. d_leaf_aabbs == NULL is kk_trace_accel_build. */
+int kk_trace_accel_build_with_leaf_boxes(const kk_lbvh_device_data *d_lbvh, const float *d_positions,
+                                         const uint32_t *d_face_pos_idx, uint32_t face_num,
+                                         uint32_t compacted_face_num, const float *d_leaf_aabbs,
+                                         void *d_accel, size_t accel_bytes, void *stream);
 size_t kk_closest_hit_accel_workspace_bytes(uint32_t ray_num);
 /* d_counters (optional, uint64[16], zeroed by the caller): [0] 128-byte node records visited,
  * [1] triangles tested, [2] rays traced; diagnostics of the kernel's lane use: [3] passes of the wave

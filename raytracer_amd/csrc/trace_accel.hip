@@ -60,7 +60,7 @@ struct alignas(256) BuildCtl {
 };
 
 struct Layout {
-    size_t header, ctl, nodes, tris, parents, rootOf, total;
+    size_t header, ctl, nodes, tris, parents, rootOf, recSrc, total;
 };
 inline Layout layout(uint32_t faceNum, uint32_t compactedNum) {
     Layout l;
@@ -72,6 +72,9 @@ inline Layout layout(uint32_t faceNum, uint32_t compactedNum) {
     l.tris = c.take(sizeof(TriRec) * static_cast<size_t>(faceNum));
     l.parents = c.take(sizeof(uint32_t) * static_cast<size_t>(nodeNum)); // parent of each binary node
     l.rootOf = c.take(sizeof(uint32_t) * static_cast<size_t>(nodeNum));  // binary root of each wide node
+    // build scratch: (sorted position, leaf's parent) of every triangle record. The padded leaf boxes,
+    // 24 B per leaf, borrow the triangle records' own space, which is written last.
+    l.recSrc = c.take(sizeof(uint2) * static_cast<size_t>(faceNum));
     l.total = c.off;
     return l;
 }
@@ -111,6 +114,62 @@ __global__ __launch_bounds__(THREADS) void parents_kernel(const kk_lbvh_device_d
         parents[ch.y] = n;
 }
 
+// The box of every leaf (its triangles' vertices), 24 B per leaf, a thread per leaf in sorted order,
+// for callers that do not hand over the LBVH build's own leaf boxes.
+__device__ __forceinline__ float leaf_pad(const kk_lbvh_node *nodes) {
+    const trav::NodeData root = trav::load_node(nodes, 0);
+    float scale = 0.f;
+    for (int a = 0; a < 3; ++a) {
+        scale = fmaxf(scale, fabsf(root.box.minPos[a]));
+        scale = fmaxf(scale, fabsf(root.box.maxPos[a]));
+        scale = fmaxf(scale, root.box.maxPos[a] - root.box.minPos[a]);
+    }
+    return LEAF_PAD * scale;
+}
+__global__ __launch_bounds__(THREADS) void leaf_boxes_kernel(const kk_lbvh_device_data *__restrict__ lbvh,
+                                                             const float *__restrict__ positions,
+                                                             const uint32_t *__restrict__ tri,
+                                                             float *__restrict__ leafBoxes) {
+    const uint32_t faceNum = lbvh->face_num, leafNum = lbvh->compacted_face_num;
+    const uint32_t l = blockIdx.x * THREADS + threadIdx.x;
+    if (l >= leafNum)
+        return;
+    const uint32_t *__restrict__ faces = lbvh->faces;
+    const uint32_t *__restrict__ compacted = lbvh->compacted_faces;
+    const uint32_t k0 = compacted[l], k1 = (l == leafNum - 1) ? faceNum : compacted[l + 1];
+    AABB b = AABB::Initial();
+    for (uint32_t k = k0; k < k1; ++k) {
+        const uint32_t fi = faces[k];
+        b.Expand(trav::load_pos(positions, tri[3ull * fi]));
+        b.Expand(trav::load_pos(positions, tri[3ull * fi + 1]));
+        b.Expand(trav::load_pos(positions, tri[3ull * fi + 2]));
+    }
+    float *o = leafBoxes + 6ull * l;
+    o[0] = b.minPos.x, o[1] = b.minPos.y, o[2] = b.minPos.z;
+    o[3] = b.maxPos.x, o[4] = b.maxPos.y, o[5] = b.maxPos.z;
+}
+
+// Triangle record w from its source (sorted position k, parent binary node of its leaf): a thread per
+// record, after the last level (the records overwrite the leaf boxes).
+__global__ __launch_bounds__(THREADS) void fill_records_kernel(const kk_lbvh_device_data *__restrict__ lbvh,
+                                                               const float *__restrict__ positions,
+                                                               const uint32_t *__restrict__ tri,
+                                                               const uint2 *__restrict__ recSrc,
+                                                               TriRec *__restrict__ recs) {
+    const uint32_t w = blockIdx.x * THREADS + threadIdx.x;
+    if (w >= lbvh->face_num)
+        return;
+    const uint2 src = recSrc[w];
+    const uint32_t fi = lbvh->faces[src.x];
+    const f3 a = trav::load_pos(positions, tri[3ull * fi]);
+    const f3 b = trav::load_pos(positions, tri[3ull * fi + 1]);
+    const f3 c = trav::load_pos(positions, tri[3ull * fi + 2]);
+    uint4 *o = reinterpret_cast<uint4 *>(recs + w);
+    o[0] = make_uint4(__float_as_uint(a.x), __float_as_uint(a.y), __float_as_uint(a.z), fi);
+    o[1] = make_uint4(__float_as_uint(b.x), __float_as_uint(b.y), __float_as_uint(b.z), src.y);
+    o[2] = make_uint4(__float_as_uint(c.x), __float_as_uint(c.y), __float_as_uint(c.z), src.x);
+}
+
 constexpr int BT = 128; // threads of a collapse workgroup: 16 KB of slot storage in LDS
 
 // Runs between two levels: the wide nodes reserved so far end the level that is built next.
@@ -120,44 +179,35 @@ __global__ void close_level_kernel(BuildCtl *ctl, Header *hdr, int level) {
     hdr->wideNum = total;
 }
 
-// One level of wide nodes: thread w opens the binary subtree rootOf[w] into at most eight slots,
-// reserves its children's wide nodes and its triangles' records, and writes all three. Slot boxes
-// are quantised as they are met, against the subtree's own box (grown by the leaf pad), which
-// contains them all.
-__global__ __launch_bounds__(BT) void collapse_level_kernel(
-    const kk_lbvh_device_data *__restrict__ lbvh, const float *__restrict__ positions,
-    const uint32_t *__restrict__ tri, Wide8 *__restrict__ out, TriRec *__restrict__ recs,
-    uint32_t *__restrict__ rootOf, BuildCtl *ctl, int level) {
-    __shared__ uint2 s_q[8][BT];      // x: minx miny minz maxx (bytes), y: maxy maxz
-    __shared__ uint32_t s_ref[8][BT]; // binary node, or LEAF | leaf index
-    __shared__ uint32_t s_aux[8][BT]; // leaf: its parent binary node; subtree: half box area (float)
+// One level of wide nodes [start, end): thread w opens the binary subtree rootOf[w] into at most eight
+// slots, reserves its children's wide nodes and its triangles' records, and writes the node and the
+// records' sources. Slot boxes are quantised as they are met, against the subtree's own box (grown by
+// the leaf pad), which contains them all. Workgroup `group` of `groups` takes every groups-th batch.
+struct CollapseLds {
+    uint2 q[8][BT];      // x: minx miny minz maxx (bytes), y: maxy maxz
+    uint32_t ref[8][BT]; // binary node, or LEAF | leaf index
+    uint32_t aux[8][BT]; // leaf: its parent binary node; subtree: half box area (float)
+};
+__device__ __forceinline__ void collapse_range(CollapseLds &lds, const kk_lbvh_device_data *__restrict__ lbvh,
+                                               const float *__restrict__ leafBoxes, Wide8 *__restrict__ out,
+                                               uint2 *__restrict__ recSrc, uint32_t *rootOf, BuildCtl *ctl,
+                                               uint32_t start, uint32_t end, uint32_t group, uint32_t groups) {
+    auto &s_q = lds.q;
+    auto &s_ref = lds.ref;
+    auto &s_aux = lds.aux;
     const int tid = threadIdx.x, lane = tid & 63;
-    const uint32_t start = ctl->bounds[level], end = ctl->bounds[level + 1];
-    if (start >= end)
-        return;
     const kk_lbvh_node *__restrict__ nodes = lbvh->internal_nodes;
-    const uint32_t *__restrict__ faces = lbvh->faces;
     const uint32_t *__restrict__ compacted = lbvh->compacted_faces;
     const uint32_t faceNum = lbvh->face_num, leafNum = lbvh->compacted_face_num;
 
-    float pad;
-    {
-        const trav::NodeData root = trav::load_node(nodes, 0);
-        float scale = 0.f;
-        for (int a = 0; a < 3; ++a) {
-            scale = fmaxf(scale, fabsf(root.box.minPos[a]));
-            scale = fmaxf(scale, fabsf(root.box.maxPos[a]));
-            scale = fmaxf(scale, root.box.maxPos[a] - root.box.minPos[a]);
-        }
-        pad = LEAF_PAD * scale;
-    }
+    const float pad = leaf_pad(nodes);
     auto runOf = [&](uint32_t leaf, uint32_t &k0, uint32_t &k1) {
         const uint32_t l = leaf & LEAF_MASK;
         k0 = compacted[l];
         k1 = (l == leafNum - 1) ? faceNum : compacted[l + 1];
     };
 
-    for (uint32_t base = start + blockIdx.x * BT; base < end; base += gridDim.x * BT) {
+    for (uint32_t base = start + group * BT; base < end; base += groups * BT) {
         const uint32_t w = base + tid;
         const bool valid = w < end;
         int cN = 0;
@@ -182,17 +232,9 @@ __global__ __launch_bounds__(BT) void collapse_level_kernel(
                 AABB b;
                 uint32_t aux;
                 if (c & LEAF) {
-                    uint32_t k0, k1;
-                    runOf(c, k0, k1);
-                    b = AABB::Initial();
-                    for (uint32_t k = k0; k < k1; ++k) {
-                        const uint32_t fi = faces[k];
-                        b.Expand(trav::load_pos(positions, tri[3ull * fi]));
-                        b.Expand(trav::load_pos(positions, tri[3ull * fi + 1]));
-                        b.Expand(trav::load_pos(positions, tri[3ull * fi + 2]));
-                    }
-                    b.minPos = b.minPos - pad;
-                    b.maxPos = b.maxPos + pad;
+                    const float *lb = leafBoxes + 6ull * (c & LEAF_MASK);
+                    b.minPos = F3(lb[0], lb[1], lb[2]) - pad;
+                    b.maxPos = F3(lb[3], lb[4], lb[5]) + pad;
                     aux = parent;
                 } else {
                     b = trav::load_node(nodes, c).box;
@@ -326,16 +368,8 @@ __global__ __launch_bounds__(BT) void collapse_level_kernel(
             rec.off16[sl] = static_cast<uint16_t>(run < 65535u ? run : 65535u);
             rec.cnt16[sl] = static_cast<uint16_t>(k1 - k0 < 65535u ? k1 - k0 : 65535u);
             const uint32_t parent = s_aux[j][tid];
-            for (uint32_t k = k0; k < k1; ++k, ++run) {
-                const uint32_t fi = faces[k];
-                const f3 a = trav::load_pos(positions, tri[3ull * fi]);
-                const f3 b = trav::load_pos(positions, tri[3ull * fi + 1]);
-                const f3 c = trav::load_pos(positions, tri[3ull * fi + 2]);
-                uint4 *o = reinterpret_cast<uint4 *>(recs + triBase + run);
-                o[0] = make_uint4(__float_as_uint(a.x), __float_as_uint(a.y), __float_as_uint(a.z), fi);
-                o[1] = make_uint4(__float_as_uint(b.x), __float_as_uint(b.y), __float_as_uint(b.z), parent);
-                o[2] = make_uint4(__float_as_uint(c.x), __float_as_uint(c.y), __float_as_uint(c.z), k);
-            }
+            for (uint32_t k = k0; k < k1; ++k, ++run)
+                recSrc[triBase + run] = make_uint2(k, parent);
         }
         const bool huge = ct > 65535u;
         rec.leafMask = leafMask | (longest > 15u ? LONG_RUN : 0u) | (huge ? HUGE_RUN : 0u);
@@ -347,6 +381,48 @@ __global__ __launch_bounds__(BT) void collapse_level_kernel(
 #pragma unroll
         for (int i = 0; i < 8; ++i)
             o[i] = src[i];
+    }
+}
+
+__global__ __launch_bounds__(BT) void collapse_level_kernel(
+    const kk_lbvh_device_data *__restrict__ lbvh, const float *__restrict__ leafBoxes,
+    Wide8 *__restrict__ out, uint2 *__restrict__ recSrc, uint32_t *__restrict__ rootOf, BuildCtl *ctl,
+    int level) {
+    __shared__ CollapseLds lds;
+    const uint32_t start = ctl->bounds[level], end = ctl->bounds[level + 1];
+    if (start >= end)
+        return;
+    collapse_range(lds, lbvh, leafBoxes, out, recSrc, rootOf, ctl, start, end, blockIdx.x, gridDim.x);
+}
+
+// Levels from `level` on, in one workgroup: past the first dozen levels a tree has few nodes left (or
+// none), and a launch per level would cost more than the work. What one level wrote is read by the
+// next after a device-scope fence and a barrier.
+__global__ __launch_bounds__(BT) void collapse_tail_kernel(
+    const kk_lbvh_device_data *__restrict__ lbvh, const float *__restrict__ leafBoxes,
+    Wide8 *__restrict__ out, uint2 *__restrict__ recSrc, uint32_t *rootOf, BuildCtl *ctl, Header *hdr,
+    int level) {
+    __shared__ CollapseLds lds;
+    __shared__ uint32_t s_range[2];
+    for (; level < MAX_LEVELS; ++level) {
+        if (threadIdx.x == 0) {
+            s_range[0] = __atomic_load_n(&ctl->bounds[level], __ATOMIC_RELAXED);
+            s_range[1] = __atomic_load_n(&ctl->bounds[level + 1], __ATOMIC_RELAXED);
+        }
+        __syncthreads();
+        const uint32_t start = s_range[0], end = s_range[1];
+        if (start >= end)
+            return; // an empty level: nothing below it either
+        collapse_range(lds, lbvh, leafBoxes, out, recSrc, rootOf, ctl, start, end, 0u, 1u);
+        __threadfence();
+        __syncthreads();
+        if (threadIdx.x == 0) { // what close_level_kernel does between launches
+            const uint32_t total = __atomic_load_n(&ctl->wideCount, __ATOMIC_RELAXED);
+            __atomic_store_n(&ctl->bounds[level + 2], total, __ATOMIC_RELAXED);
+            hdr->wideNum = total;
+        }
+        __threadfence();
+        __syncthreads();
     }
 }
 
@@ -699,10 +775,12 @@ extern "C" int kk_trace_accel_layout(uint32_t face_num, uint32_t compacted_face_
     return KK_OK;
 }
 
-extern "C" int kk_trace_accel_build(const kk_lbvh_device_data *d_lbvh, const float *d_positions,
-                                    const uint32_t *d_face_pos_idx, uint32_t face_num,
-                                    uint32_t compacted_face_num, void *d_accel, size_t accel_bytes,
-                                    void *stream_) {
+extern "C" int kk_trace_accel_build_with_leaf_boxes(const kk_lbvh_device_data *d_lbvh,
+                                                    const float *d_positions,
+                                                    const uint32_t *d_face_pos_idx, uint32_t face_num,
+                                                    uint32_t compacted_face_num,
+                                                    const float *d_leaf_aabbs, void *d_accel,
+                                                    size_t accel_bytes, void *stream_) {
     using namespace kk;
     using namespace kk::accel;
     KK_REQUIRE(d_lbvh && d_positions && d_face_pos_idx && d_accel, "null pointer");
@@ -717,25 +795,47 @@ extern "C" int kk_trace_accel_build(const kk_lbvh_device_data *d_lbvh, const flo
     auto *hdr = reinterpret_cast<Header *>(b + l.header);
     auto *ctl = reinterpret_cast<BuildCtl *>(b + l.ctl);
     auto *rootOf = reinterpret_cast<uint32_t *>(b + l.rootOf);
+    auto *wide = reinterpret_cast<Wide8 *>(b + l.nodes);
     init_build_kernel<<<1, 1, 0, stream>>>(d_lbvh, hdr, ctl, rootOf, nodeNum);
     KK_LAUNCH_CHECK();
     parents_kernel<<<div_up(nodeNum, THREADS), THREADS, 0, stream>>>(
         d_lbvh, reinterpret_cast<uint32_t *>(b + l.parents), nodeNum);
     KK_LAUNCH_CHECK();
+    auto *recSrc = reinterpret_cast<uint2 *>(b + l.recSrc);
+    const float *leafBoxes = d_leaf_aabbs;
+    if (!leafBoxes) { // made here, where the triangle records go at the end
+        float *own = reinterpret_cast<float *>(b + l.tris);
+        leaf_boxes_kernel<<<div_up(compacted_face_num, THREADS), THREADS, 0, stream>>>(
+            d_lbvh, d_positions, d_face_pos_idx, own);
+        KK_LAUNCH_CHECK();
+        leafBoxes = own;
+    }
     uint32_t grid = div_up(nodeNum, BT);
     if (grid > 2048)
         grid = 2048;
-    for (int level = 0; level < MAX_LEVELS; ++level) {
+    constexpr int TAIL_FROM = 12; // a launch per level up to here, one workgroup for the rest
+    for (int level = 0; level < TAIL_FROM; ++level) {
         // level l has at most 8^l nodes
         const uint32_t g = level < 7 ? (grid < div_up(1u << (3 * level), BT) ? grid : div_up(1u << (3 * level), BT)) : grid;
-        collapse_level_kernel<<<g, BT, 0, stream>>>(d_lbvh, d_positions, d_face_pos_idx,
-                                                    reinterpret_cast<Wide8 *>(b + l.nodes),
-                                                    reinterpret_cast<TriRec *>(b + l.tris), rootOf, ctl, level);
+        collapse_level_kernel<<<g, BT, 0, stream>>>(d_lbvh, leafBoxes, wide, recSrc, rootOf, ctl, level);
         KK_LAUNCH_CHECK();
         close_level_kernel<<<1, 1, 0, stream>>>(ctl, hdr, level);
         KK_LAUNCH_CHECK();
     }
+    collapse_tail_kernel<<<1, BT, 0, stream>>>(d_lbvh, leafBoxes, wide, recSrc, rootOf, ctl, hdr, TAIL_FROM);
+    KK_LAUNCH_CHECK();
+    fill_records_kernel<<<div_up(face_num, THREADS), THREADS, 0, stream>>>(
+        d_lbvh, d_positions, d_face_pos_idx, recSrc, reinterpret_cast<TriRec *>(b + l.tris));
+    KK_LAUNCH_CHECK();
     return KK_OK;
+}
+
+extern "C" int kk_trace_accel_build(const kk_lbvh_device_data *d_lbvh, const float *d_positions,
+                                    const uint32_t *d_face_pos_idx, uint32_t face_num,
+                                    uint32_t compacted_face_num, void *d_accel, size_t accel_bytes,
+                                    void *stream_) {
+    return kk_trace_accel_build_with_leaf_boxes(d_lbvh, d_positions, d_face_pos_idx, face_num,
+                                                compacted_face_num, nullptr, d_accel, accel_bytes, stream_);
 }
 
 extern "C" size_t kk_closest_hit_accel_workspace_bytes(uint32_t ray_num) {

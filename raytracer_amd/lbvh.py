@@ -134,10 +134,13 @@ class LBVH:
         if rebuild or getattr(self, "_accel_stale", False):
             self._accel_stale = False
             with torch.cuda.device(self.device):
-                _lib.check(l.kk_trace_accel_build(self.GetDeivceDataDevicePtr(), self.d_positions.data_ptr(),
-                                                  self.d_face_pos_idx.data_ptr(), N, M,
-                                                  self.d_accel.data_ptr(), self.d_accel.numel(),
-                                                  _lib.current_stream_ptr()), "kk_trace_accel_build")
+                # a tree built here still has its leaf boxes in the build workspace; a received one has not
+                ws = getattr(self, "d_workspace", None)
+                leaf_boxes = ws.data_ptr() + self.ws_layout.leaf_aabbs if ws is not None else None
+                _lib.check(l.kk_trace_accel_build_with_leaf_boxes(
+                    self.GetDeivceDataDevicePtr(), self.d_positions.data_ptr(), self.d_face_pos_idx.data_ptr(),
+                    N, M, leaf_boxes, self.d_accel.data_ptr(), self.d_accel.numel(),
+                    _lib.current_stream_ptr()), "kk_trace_accel_build_with_leaf_boxes")
         return self.d_accel
 
     # -- read-back helpers (parity tests, logs) --------------------------------------------------------

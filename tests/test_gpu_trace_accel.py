@@ -136,3 +136,23 @@ def test_wide_tree_with_long_runs_and_tiny_meshes():
         b = LBVH(DEV)
         b.BuildFrom(p, t)
         _check(b, p, t)
+
+
+def test_build_without_the_lbvh_leaf_boxes():
+    """kk_trace_accel_build makes the leaf boxes itself (LBVH.trace_accel hands over the ones in the LBVH
+    workspace): the tree it leaves in the same buffer passes the same checks."""
+    pos, tri = syn.triangle_soup(30_000, half_extent=0.03)
+    pos = pos.copy().reshape(-1, 3, 3)
+    pos[::5] = pos[::5] * np.float32(1e-4) + np.float32(0.25)  # leaves of several triangles too
+    pos = pos.reshape(-1, 3)
+    bvh = LBVH(DEV)
+    bvh.BuildFrom(pos, tri)
+    accel = bvh.trace_accel()
+    N, M = bvh._accel_sizes
+    accel.zero_()
+    _lib.check(_lib.lib().kk_trace_accel_build(bvh.GetDeivceDataDevicePtr(), bvh.d_positions.data_ptr(),
+                                               bvh.d_face_pos_idx.data_ptr(), N, M, accel.data_ptr(),
+                                               accel.numel(), _lib.current_stream_ptr()),
+               "kk_trace_accel_build")
+    torch.cuda.synchronize()
+    _check(bvh, pos, tri)
