@@ -65,8 +65,14 @@ def main():
         dist = dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device(f"cuda:{local_rank}"))
+        if os.environ.get("KK_BENCH_REHEARSAL") == "1":
+            # every rank on GPU 0 over gloo: runs the N > 1 control flow on a one-GPU box (RCCL refuses
+            # two ranks on one device); its numbers mean nothing
+            local_rank = 0
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device(f"cuda:{local_rank}"))
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
     N, R, K, W = args.tris, args.rays, args.steps, args.warmup

@@ -136,7 +136,15 @@ def gather_stripes(rgba: torch.Tensor, world: int, rank: int, dst: int = 0, scra
     padded[:H] = rgba
     view = padded.view(n, STRIPE_ROWS, W, 4)
     send[:len(mine)] = view[rank::world]
-    dist.gather(send, scratch["recv"], dst=dst)
+    if send.is_cuda and dist.get_backend() == "gloo":
+        # gloo gathers host tensors only (rehearsals of the multi-rank path on one GPU)
+        host = [torch.empty(send.shape, dtype=send.dtype) for _ in range(world)] if rank == dst else None
+        dist.gather(send.cpu(), host, dst=dst)
+        if rank == dst:
+            for r in range(world):
+                scratch["recv"][r].copy_(host[r])
+    else:
+        dist.gather(send, scratch["recv"], dst=dst)
     if rank == dst:
         for r in range(world):
             cnt = len(range(r, n, world))
