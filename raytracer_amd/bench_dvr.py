@@ -1,6 +1,6 @@
 """DVR leg of the benchmark: Kingsnake-shaped 1024 x 1024 x 795 uint8 volume at 3840 x 2160, README
-Kingsnake transfer function, log2Dims {5,4,3}, sampling rate 3, maxAlpha 0.9, depth boxes on; frames of
-the reference's own perf orbit (0.5 degrees per frame, app/dvr_dpbx_vdb.cpp:349-368). With several
+Kingsnake transfer function, log2Dims {5,4,3}, sampling rate 3, maxAlpha 0.9, depth boxes on; the 720
+frames of the reference's own perf orbit (0.5 degrees per frame, app/dvr_dpbx_vdb.cpp:349-368). With several
 ranks the VDB is built on rank 0 and broadcast, each rank renders its round-robin 16-row stripes and the
 stripes are gathered to rank 0 once per frame."""
 from __future__ import annotations
@@ -20,7 +20,7 @@ from .ray_caster import FrameBuffer, RayCaster, TransferFunctionTable
 HBM_PEAK_GBPS = 8000.0
 
 
-def run(dev: str, world: int, rank: int, dist=None, frames: int = 120, warmup: int = 8,
+def run(dev: str, world: int, rank: int, dist=None, frames: int = 720, warmup: int = 8,
         dim=(1024, 1024, 795), size=(3840, 2160), cpu_rows: int = 24, with_cpu: bool = True,
         workload: str = "kingsnake") -> dict:
     """workload "kingsnake": the 4K case above. "head": Head-shape 128x256x256 uint8 volume, README Head
