@@ -414,7 +414,9 @@ typedef struct kk_dvr_frame {
 /* One frame restricted to pixel rows [y0, y1) (row 0 = bottom row): d_rgba uint8[H][W][4] with alpha =
  * accumulated opacity. h_vdb is the HOST copy of the device-data struct (its pointers are device
  * pointers). d_tf float[256][4]. d_counters (optional, uint64[2], zeroed by the caller) accumulates
- * samples taken and leaf bricks entered. */
+ * samples taken and leaf bricks entered. Fails (KK_ERR_INVALID) when a voxs_per_child entry is not a
+ * power of two: kk_vdb_plan makes them products of the 2^log2_dims, and the marcher scales by them
+ * where the reference divides, which is the same value for powers of two only. */
 int kk_dvr_render_u8(const kk_vdb_device_data *h_vdb, const float *d_tf, const kk_dvr_params *h_params,
                      const kk_dvr_frame *h_frame, uint8_t *d_rgba, int width, int height, int y0,
                      int y1, unsigned long long *d_counters, void *stream);
