@@ -20,8 +20,12 @@ namespace vdb {
 constexpr int THREADS = 256;
 constexpr int MAX_RNGS = 8;
 
+// The empty scalar ranges as kernel arguments: lo | hi << 16 per range. Kernels read them at constant
+// positions (loops over the ranges are unrolled and leave at the count, which is the same for every
+// lane), so they stay in scalar registers; indexed with a run-time position they were fetched from
+// memory again for every voxel.
 template <typename T> struct Ranges {
-    T lo[MAX_RNGS], hi[MAX_RNGS];
+    uint32_t b[MAX_RNGS];
     uint32_t n;
 };
 
@@ -33,10 +37,16 @@ __device__ __forceinline__ T voxelAt(const T *__restrict__ vol, int dx, int dy, 
     return vol[(static_cast<size_t>(z) * dy + y) * dx + x];
 }
 
+// number of ranges that hold v (the reference counts (voxel, range) pairs, dpbx_vdb.cu:345-385)
 template <typename T> __device__ __forceinline__ uint32_t rangeHits(T v, const Ranges<T> &r) {
     uint32_t c = 0;
-    for (uint32_t i = 0; i < r.n; ++i)
-        c += (v >= r.lo[i] && v <= r.hi[i]) ? 1u : 0u;
+    const uint32_t x = v;
+#pragma unroll
+    for (uint32_t i = 0; i < MAX_RNGS; ++i) {
+        if (i >= r.n)
+            break;
+        c += (x >= (r.b[i] & 0xffffu) && x <= (r.b[i] >> 16)) ? 1u : 0u;
+    }
     return c;
 }
 
@@ -76,8 +86,14 @@ __global__ __launch_bounds__(THREADS) void classify_wide_kernel(const T *__restr
             const uint4 w = *reinterpret_cast<const uint4 *>(vol + (static_cast<size_t>(z) * dy + y) * dx + x);
             const T *v = reinterpret_cast<const T *>(&w);
 #pragma unroll
-            for (int i = 0; i < PER; ++i)
-                h += rangeHits(v[i], rngs);
+            for (uint32_t k = 0; k < MAX_RNGS; ++k) { // one range against the whole piece at a time
+                if (k >= rngs.n)
+                    break;
+                const uint32_t lo = rngs.b[k] & 0xffffu, hi = rngs.b[k] >> 16;
+#pragma unroll
+                for (int i = 0; i < PER; ++i)
+                    h += (static_cast<uint32_t>(v[i]) >= lo && static_cast<uint32_t>(v[i]) <= hi) ? 1u : 0u;
+            }
         } else
             h = PER * rangeHits(static_cast<T>(0), rngs); // outside the volume reads as 0
 #pragma unroll
@@ -285,10 +301,8 @@ template <typename T> int makeRanges(const T *h, uint32_t n, Ranges<T> &r) {
     KK_REQUIRE(n <= MAX_RNGS, "too many empty scalar ranges");
     KK_REQUIRE(n == 0 || h != nullptr, "null pointer");
     r.n = n;
-    for (uint32_t i = 0; i < n; ++i) {
-        r.lo[i] = h[2 * i];
-        r.hi[i] = h[2 * i + 1];
-    }
+    for (uint32_t i = 0; i < MAX_RNGS; ++i)
+        r.b[i] = i < n ? static_cast<uint32_t>(h[2 * i]) | (static_cast<uint32_t>(h[2 * i + 1]) << 16) : 0xffffu;
     return KK_OK;
 }
 

@@ -1,6 +1,9 @@
 """Where the wall time of DepthBoxVDB.BuildFrom goes (Kingsnake shape), cold and warm."""
+import os
+import sys
 import time
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 
