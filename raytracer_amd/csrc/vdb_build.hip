@@ -171,11 +171,36 @@ __global__ __launch_bounds__(FILL_THREADS) void fill_atlas_lds_kernel(const T *_
     T *__restrict__ out = atlas + brickVox * blockIdx.x;
     const bool depthBox = apronDepWid != apronWid;
     const int tid = threadIdx.x;
-    for (int v = tid; v < static_cast<int>(brickVox); v += FILL_THREADS) {
-        const int ax = v % A, ay = (v / A) % A, az = v / A2;
-        s_vox[v] = voxelAt(vol, dx, dy, dz, leaf.pos[0] + ax - apronDepWid, leaf.pos[1] + ay - apronDepWid,
-                           leaf.pos[2] + az - apronDepWid);
-    }
+    // Voxels move in 4-byte pieces where a row holds a whole number of them (A = 36, 20, 12 ... with
+    // depth boxes): PER voxels per load, store and thread pass. The source pieces start two bytes off a
+    // 4-byte boundary, which the memory system takes.
+    constexpr int PER = 4 / sizeof(T);
+    const bool pieces = A % PER == 0;
+    if (pieces) {
+        const int rowPieces = A / PER;
+        uint32_t *s_vox4 = reinterpret_cast<uint32_t *>(s_vox);
+        for (int g = tid; g < static_cast<int>(brickVox) / PER; g += FILL_THREADS) {
+            const int j = g % rowPieces, ay = (g / rowPieces) % A, az = g / (rowPieces * A);
+            const int x = leaf.pos[0] + j * PER - apronDepWid, y = leaf.pos[1] + ay - apronDepWid,
+                      z = leaf.pos[2] + az - apronDepWid;
+            uint32_t w = 0;
+            if (y >= 0 && y < dy && z >= 0 && z < dz) {
+                const T *src = vol + (static_cast<size_t>(z) * dy + y) * dx;
+                if (x >= 0 && x + PER <= dx)
+                    __builtin_memcpy(&w, src + x, 4);
+                else
+                    for (int i = 0; i < PER; ++i)
+                        if (x + i >= 0 && x + i < dx)
+                            w |= static_cast<uint32_t>(src[x + i]) << (8 * sizeof(T) * i);
+            }
+            s_vox4[g] = w;
+        }
+    } else
+        for (int v = tid; v < static_cast<int>(brickVox); v += FILL_THREADS) {
+            const int ax = v % A, ay = (v / A) % A, az = v / A2;
+            s_vox[v] = voxelAt(vol, dx, dy, dz, leaf.pos[0] + ax - apronDepWid, leaf.pos[1] + ay - apronDepWid,
+                               leaf.pos[2] + az - apronDepWid);
+        }
     __syncthreads();
     if (!depthBox) {
         for (int v = tid; v < static_cast<int>(brickVox); v += FILL_THREADS)
@@ -204,40 +229,50 @@ __global__ __launch_bounds__(FILL_THREADS) void fill_atlas_lds_kernel(const T *_
     }
     __syncthreads();
     const unsigned long long field = (1ull << (B - 1)) - 1ull; // the B - 1 positions a march can stop at
-    for (int v = tid; v < static_cast<int>(brickVox); v += FILL_THREADS) {
-        const int ax = v % A, ay = (v / A) % A, az = v / A2;
-        const int dirX = ax == 0 ? 1 : ax == A - 1 ? -1 : 0;
-        const int dirY = ay == 0 ? 1 : ay == A - 1 ? -1 : 0;
-        const int dirZ = az == 0 ? 1 : az == A - 1 ? -1 : 0;
-        const int faces = (dirX != 0) + (dirY != 0) + (dirZ != 0);
-        T value;
-        if (faces == 0)
-            value = s_vox[v];
-        else if (faces > 1)
-            value = 0;
-        else {
-            // the 3 x 3 window spans the two other axes; (o, i) = the centre's row coordinates
-            const int d = dirX != 0 ? 0 : dirY != 0 ? 1 : 2;
-            const int o = d == 2 ? ay : az, i = d == 0 ? ay : ax;
-            const int dir = dirX + dirY + dirZ;
-            const unsigned long long *rows = s_mask + d * A2;
-            unsigned long long w = 0;
+    const int group = pieces ? PER : 1; // voxels a thread makes per pass, stored as one piece
+    for (int v0 = tid * group; v0 < static_cast<int>(brickVox); v0 += FILL_THREADS * group) {
+        uint32_t packed = 0;
+        for (int sub = 0; sub < group; ++sub) {
+            const int v = v0 + sub;
+            const int ax = v % A, ay = (v / A) % A, az = v / A2;
+            const int dirX = ax == 0 ? 1 : ax == A - 1 ? -1 : 0;
+            const int dirY = ay == 0 ? 1 : ay == A - 1 ? -1 : 0;
+            const int dirZ = az == 0 ? 1 : az == A - 1 ? -1 : 0;
+            const int faces = (dirX != 0) + (dirY != 0) + (dirZ != 0);
+            T value;
+            if (faces == 0)
+                value = s_vox[v];
+            else if (faces > 1)
+                value = 0;
+            else {
+                // the 3 x 3 window spans the two other axes; (o, i) = the centre's row coordinates
+                const int d = dirX != 0 ? 0 : dirY != 0 ? 1 : 2;
+                const int o = d == 2 ? ay : az, i = d == 0 ? ay : ax;
+                const int dir = dirX + dirY + dirZ;
+                const unsigned long long *rows = s_mask + d * A2;
+                unsigned long long w = 0;
 #pragma unroll
-            for (int t = 0; t < 9; ++t)
-                w |= rows[(o + t / 3 - 1) * A + (i + t % 3 - 1)];
-            int dep = B - 1;
-            if (dir > 0) { // from brick position 0 upwards: positions 0 .. B - 2
-                const unsigned long long f = (w >> apronDepWid) & field;
-                if (f)
-                    dep = __ffsll(static_cast<long long>(f)) - 1;
-            } else { // from brick position B - 1 downwards: positions B - 1 .. 1
-                const unsigned long long f = (w >> (apronDepWid + 1)) & field;
-                if (f)
-                    dep = (B - 2) - (63 - __clzll(static_cast<long long>(f)));
+                for (int t = 0; t < 9; ++t)
+                    w |= rows[(o + t / 3 - 1) * A + (i + t % 3 - 1)];
+                int dep = B - 1;
+                if (dir > 0) { // from brick position 0 upwards: positions 0 .. B - 2
+                    const unsigned long long f = (w >> apronDepWid) & field;
+                    if (f)
+                        dep = __ffsll(static_cast<long long>(f)) - 1;
+                } else { // from brick position B - 1 downwards: positions B - 1 .. 1
+                    const unsigned long long f = (w >> (apronDepWid + 1)) & field;
+                    if (f)
+                        dep = (B - 2) - (63 - __clzll(static_cast<long long>(f)));
+                }
+                value = static_cast<T>(dep);
             }
-            value = static_cast<T>(dep);
+            if (pieces)
+                packed |= static_cast<uint32_t>(value) << (8 * sizeof(T) * sub);
+            else
+                out[v] = value;
         }
-        out[v] = value;
+        if (pieces) // a brick starts on a 4-byte boundary when its voxel count is a multiple of PER
+            reinterpret_cast<uint32_t *>(out)[v0 / PER] = packed;
     }
 }
 
