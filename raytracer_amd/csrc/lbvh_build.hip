@@ -436,7 +436,7 @@ constexpr int REFIT_LEAVES = THREADS * REFIT_LPT; // 1024 = 32^2
 constexpr int REFIT_LOG = 10;
 constexpr int RADIX_LOG = 5; // aligned block totals exist for 32^l leaves, l = 1, 2, ...
 constexpr int MAX_TOTAL_LEVELS = 7;
-constexpr int REFIT_SPAN_BLOCKS = 1024;
+constexpr int REFIT_SPAN_BLOCKS = 4096; // sixteen lanes per crossing node (about 1 % of the nodes): 16 nodes per block and pass
 static_assert(REFIT_LEAVES == (1 << REFIT_LOG) && REFIT_LOG == 2 * RADIX_LOG, "window = 32^2 leaves");
 
 
@@ -589,44 +589,87 @@ __global__ __launch_bounds__(1024) void block_totals_kernel(
     }
 }
 
+// Sixteen lanes per window-crossing node. Its leaf range is covered, left to right, by runs of aligned
+// blocks: single leaves up to a multiple of 32, blocks of 32 up to a multiple of 1024, ... and back down
+// to single leaves at the right end. The pieces are numbered in that order, each of the sixteen lanes
+// folds a contiguous share of them and the lanes' boxes are folded in lane order; Expand keeps its
+// left operand on ties, so this is the left-to-right fold. (A thread per node walks some eighty
+// dependent loads; a whole wave per node spends more on finding the runs than on the fold.)
 __global__ __launch_bounds__(THREADS) void refit_span_kernel(
     const float *__restrict__ leafAABBs, const kk_lbvh_device_data *__restrict__ hdr,
     kk_lbvh_node *nodes, const uint32_t *__restrict__ rangeEnds, const float *__restrict__ totals,
     TotalsLayout tl, const uint32_t *__restrict__ topList, const uint32_t *__restrict__ topCount) {
+    constexpr int SPAN_LANES = 16, GROUPS = THREADS / SPAN_LANES;
+    constexpr int MAX_RUNS = 2 * (MAX_TOTAL_LEVELS + 1);
+    __shared__ uint64_t s_start[MAX_TOTAL_LEVELS + 1];
+    __shared__ uint32_t s_runLev[GROUPS][MAX_RUNS], s_runNum[GROUPS][MAX_RUNS];
+    __shared__ uint64_t s_runFirst[GROUPS][MAX_RUNS];
+    if (threadIdx.x <= MAX_TOTAL_LEVELS)
+        s_start[threadIdx.x] = tl.start[threadIdx.x];
+    __syncthreads();
     const uint32_t count = *topCount;
-    for (uint32_t e = blockIdx.x * THREADS + threadIdx.x; e < count; e += gridDim.x * THREADS) {
+    const int lane = threadIdx.x & (SPAN_LANES - 1), group = threadIdx.x / SPAN_LANES;
+    // the lanes of a group share `e`, so they stay or leave together (the shuffles below stay
+    // inside a group)
+    for (uint32_t e = blockIdx.x * GROUPS + group; e < count; e += gridDim.x * GROUPS) {
         const uint32_t i = topList[e];
         const uint32_t other = rangeEnds[i];
-        uint64_t p = i < other ? i : other;                 // next leaf to take in
+        uint64_t p = i < other ? i : other;                  // next leaf to take in
         const uint64_t end = (i < other ? other : i) + 1ull; // one past the range
-        AABB acc = AABB::Initial();
-        // climb: single leaves up to a multiple of 32, blocks of 32 up to a multiple of 1024, ...
-        uint32_t l = 0;
-        while (true) {
+        // the runs: level, first block of that level, number of blocks (the lanes of a group compute
+        // and write the same values into the group's rows)
+        uint32_t *runLev = s_runLev[group], *runNum = s_runNum[group];
+        uint64_t *runFirst = s_runFirst[group];
+        int runs = 0;
+        uint32_t total = 0, l = 0;
+        while (true) { // climb
             const uint64_t unit = 1ull << (RADIX_LOG * l), next = unit << RADIX_LOG;
-            const float *src = l == 0 ? leafAABBs : totals + 6 * tl.start[l];
-            while ((p & (next - 1)) != 0 && p + unit <= end) {
-                acc.Expand(load_box(src + 6 * (p >> (RADIX_LOG * l))));
-                p += unit;
-            }
+            const uint64_t toAlign = (p & (next - 1)) ? (next - (p & (next - 1))) >> (RADIX_LOG * l) : 0ull;
+            const uint64_t fit = (end - p) >> (RADIX_LOG * l);
+            const uint32_t n = static_cast<uint32_t>(toAlign < fit ? toAlign : fit);
+            runLev[runs] = l, runFirst[runs] = p >> (RADIX_LOG * l), runNum[runs] = n;
+            ++runs;
+            total += n;
+            p += static_cast<uint64_t>(n) * unit;
             if (l < tl.levels && (p & (next - 1)) == 0 && p + next <= end)
                 ++l;
             else
                 break;
         }
-        // descend: as many blocks of the current size as still fit, then smaller ones
-        while (true) {
-            const uint64_t unit = 1ull << (RADIX_LOG * l);
-            const float *src = l == 0 ? leafAABBs : totals + 6 * tl.start[l];
-            while (p + unit <= end) {
-                acc.Expand(load_box(src + 6 * (p >> (RADIX_LOG * l))));
-                p += unit;
-            }
+        while (true) { // descend
+            const uint32_t n = static_cast<uint32_t>((end - p) >> (RADIX_LOG * l));
+            runLev[runs] = l, runFirst[runs] = p >> (RADIX_LOG * l), runNum[runs] = n;
+            ++runs;
+            total += n;
+            p += static_cast<uint64_t>(n) << (RADIX_LOG * l);
             if (l == 0)
                 break;
             --l;
         }
-        store_box(nodes[i].aabb_min, acc);
+        const uint32_t per = (total + SPAN_LANES - 1u) / SPAN_LANES;
+        const uint32_t mine0 = lane * per, mine1 = mine0 + per < total ? mine0 + per : total;
+        AABB acc = AABB::Initial();
+        uint32_t before = 0;
+        for (int r = 0; r < runs; ++r) {
+            const uint32_t n = runNum[r];
+            const uint32_t q0 = mine0 > before ? mine0 - before : 0u;
+            const uint32_t q1 = mine1 > before ? (mine1 - before < n ? mine1 - before : n) : 0u;
+            const float *src = runLev[r] == 0 ? leafAABBs : totals + 6 * s_start[runLev[r]];
+            for (uint32_t q = q0; q < q1; ++q)
+                acc.Expand(load_box(src + 6 * (runFirst[r] + q)));
+            before += n;
+        }
+        for (int o = 1; o < SPAN_LANES; o <<= 1) {
+            AABB right;
+            right.minPos = {__shfl_down(acc.minPos.x, o, SPAN_LANES), __shfl_down(acc.minPos.y, o, SPAN_LANES),
+                            __shfl_down(acc.minPos.z, o, SPAN_LANES)};
+            right.maxPos = {__shfl_down(acc.maxPos.x, o, SPAN_LANES), __shfl_down(acc.maxPos.y, o, SPAN_LANES),
+                            __shfl_down(acc.maxPos.z, o, SPAN_LANES)};
+            if (lane + o < SPAN_LANES)
+                acc.Expand(right);
+        }
+        if (lane == 0)
+            store_box(nodes[i].aabb_min, acc);
     }
 }
 
