@@ -329,13 +329,13 @@ constexpr int KARRAS_WIN = THREADS + 2 * KARRAS_HALO;
 struct Codes {
     const uint32_t *__restrict__ global;
     const uint32_t *lds;
-    int64_t winStart;
-    __device__ __forceinline__ uint32_t operator[](int64_t j) const {
-        const int64_t r = j - winStart;
+    int winStart;
+    __device__ __forceinline__ uint32_t operator[](int j) const {
+        const int r = j - winStart;
         return (r >= 0 && r < KARRAS_WIN) ? lds[r] : global[j];
     }
 };
-__device__ __forceinline__ int delta(const Codes &m, uint32_t mi, int64_t j, int64_t inodeNum) {
+__device__ __forceinline__ int delta(const Codes &m, uint32_t mi, int j, int inodeNum) {
     if (j < 0 || j > inodeNum)
         return -1;
     const uint32_t x = mi ^ m[j];
@@ -351,31 +351,33 @@ __global__ __launch_bounds__(THREADS) void karras_links_kernel(
     uint32_t *__restrict__ leafParents, uint32_t *__restrict__ rangeEnds) {
     __shared__ uint32_t s_codes[KARRAS_WIN];
     const uint32_t M = hdr->compacted_face_num;
-    const int64_t inodeNum = static_cast<int64_t>(M) - 1;
-    const int64_t blockFirst = static_cast<int64_t>(blockIdx.x) * THREADS;
+    // 32-bit positions: the leaf count is below 2^30 and a search looks at most one power of two past
+    // the range, so i +- offset stays inside an int
+    const int inodeNum = static_cast<int>(M) - 1;
+    const int blockFirst = static_cast<int>(blockIdx.x) * THREADS;
     if (blockFirst >= inodeNum)
         return;
     Codes mortons{mortonsGlobal, s_codes, blockFirst - KARRAS_HALO};
     for (int r = threadIdx.x; r < KARRAS_WIN; r += THREADS) {
-        const int64_t j = mortons.winStart + r;
+        const int j = mortons.winStart + r;
         s_codes[r] = (j >= 0 && j <= inodeNum) ? mortonsGlobal[j] : 0u;
     }
     __syncthreads();
-    const int64_t i = blockFirst + threadIdx.x;
+    const int i = blockFirst + static_cast<int>(threadIdx.x);
     if (i >= inodeNum)
         return;
     const uint32_t mi = mortons[i];
 
     const int commLft = delta(mortons, mi, i - 1, inodeNum);
     const int commRht = delta(mortons, mi, i + 1, inodeNum);
-    const int64_t d = (commLft <= commRht) ? 1 : -1;
+    const int d = (commLft <= commRht) ? 1 : -1;
 
     int cmp = delta(mortons, mi, i - d, inodeNum);
-    int64_t offsMax = 2;
+    int offsMax = 2;
     while (delta(mortons, mi, i + d * offsMax, inodeNum) > cmp)
         offsMax <<= 1;
 
-    int64_t offs = 0;
+    int offs = 0;
     while (true) {
         offsMax >>= 1;
         if (offsMax < 1)
@@ -383,7 +385,7 @@ __global__ __launch_bounds__(THREADS) void karras_links_kernel(
         if (delta(mortons, mi, i + d * (offsMax + offs), inodeNum) > cmp)
             offs += offsMax;
     }
-    const int64_t iMax = i + d * offs;
+    const int iMax = i + d * offs;
     cmp = delta(mortons, mi, iMax, inodeNum);
 
     offsMax = offs;
@@ -397,11 +399,11 @@ __global__ __launch_bounds__(THREADS) void karras_links_kernel(
         if (offsMax == 1)
             break;
     }
-    const int64_t split = i + d * offs + (d < 0 ? -1 : 0);
+    const int split = i + d * offs + (d < 0 ? -1 : 0);
 
     uint32_t lft = static_cast<uint32_t>(split);
     uint32_t rht = static_cast<uint32_t>(split + 1);
-    const int64_t lo = i < iMax ? i : iMax, hi = i < iMax ? iMax : i;
+    const int lo = i < iMax ? i : iMax, hi = i < iMax ? iMax : i;
     if (PARENTS) {
         (lo == split ? leafParents : nodeParents)[lft] = static_cast<uint32_t>(i);
         (hi == split + 1 ? leafParents : nodeParents)[rht] = static_cast<uint32_t>(i);
