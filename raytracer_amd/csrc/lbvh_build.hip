@@ -8,10 +8,9 @@
 //   count_heads/scan/compact    : run starts of equal codes -> leaves          (algorithm.h:11-41)
 //   leaf_aabb                   : one box per run                              (lbvh.cu:186-219)
 //   karras_links                : children of each internal node (+ parents)   (lbvh.cu:29-98,221-260)
-//   refit_local + refit_top     : bottom-up box union with one arrival counter per internal node
-//                                 (in LDS inside a workgroup's leaf window, global above it).
-//                                 The reference walks each node's whole subtree (lbvh.cu:265-297);
-//                                 min/max unions are exact, so both give the same bits.
+//   refit_window/block_totals/  : node boxes as in-order folds over each node's leaf range (no
+//   refit_span                    arrival counters). The reference walks each node's whole subtree
+//                                 (lbvh.cu:265-297); min/max unions are exact, so both give the same bits.
 #include "kk_host.h"
 #include "kk_math.h"
 
@@ -183,9 +182,12 @@ __global__ __launch_bounds__(THREADS) void morton_kernel(const float *__restrict
     box.Expand(load3(pos, tri[3ull * fi]));
     box.Expand(load3(pos, tri[3ull * fi + 1]));
     box.Expand(load3(pos, tri[3ull * fi + 2]));
-    // kept for the leaf boxes: gathering one 24-byte box per sorted face later costs a third of the
-    // lines that gathering its indices and vertices again would
-    store_box(faceBoxes + 6ull * fi, box);
+    // kept for the leaf boxes: gathering one box per sorted face later costs a third of the lines that
+    // gathering its indices and vertices again would. 32 bytes per face (two 16-byte pieces), so that a
+    // gathered box never straddles a 128-byte line
+    float4 *fb = reinterpret_cast<float4 *>(faceBoxes + 8ull * fi);
+    fb[0] = make_float4(box.minPos.x, box.minPos.y, box.minPos.z, box.maxPos.x);
+    fb[1] = make_float4(box.maxPos.y, box.maxPos.z, 0.f, 0.f);
     f3 c = .5f * (box.minPos + box.maxPos);
     c = (c - minPos) * invDlt;
     c.x = gmin(gmax(c.x * 1024.f, 0.f), 1023.f);
@@ -317,8 +319,14 @@ __global__ __launch_bounds__(THREADS) void leaf_aabb_kernel(
     const uint32_t beg = compacted[c];
     const uint32_t end = (c == M - 1) ? N : compacted[c + 1];
     AABB box = AABB::Initial();
-    for (uint32_t k = beg; k < end; ++k)
-        box.Expand(load_box(faceBoxes + 6ull * faces[k]));
+    for (uint32_t k = beg; k < end; ++k) {
+        const float4 *fb = reinterpret_cast<const float4 *>(faceBoxes + 8ull * faces[k]);
+        const float4 lo = fb[0], hi = fb[1];
+        AABB one;
+        one.minPos = {lo.x, lo.y, lo.z};
+        one.maxPos = {lo.w, hi.x, hi.y};
+        box.Expand(one);
+    }
     store_box(leafAABBs + 6ull * c, box);
 }
 
@@ -692,7 +700,7 @@ inline Ws layout(uint32_t N, uint32_t flags) {
     w.pub.sorted_mortons = c.take(4 * n); // keys0: Morton codes, sorted in place by the 4 passes
     w.keys1 = c.take(4 * n);
     w.vals1 = c.take(4 * n);
-    w.faceBoxes = c.take(24 * n);
+    w.faceBoxes = c.take(32 * n);
     w.pub.unsorted_mortons = (flags & KK_LBVH_KEEP_STAGES) ? c.take(4 * n) : 0;
     w.pub.unique_mortons = c.take(4 * n);
     w.pub.leaf_aabbs = c.take(24 * n);
