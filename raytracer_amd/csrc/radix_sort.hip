@@ -274,7 +274,8 @@ int sort_pairs(uint32_t *keysA, uint32_t *keysB, uint32_t *valsA, uint32_t *vals
     // ghist, counters, error and the status rows are contiguous pieces of one allocation
     KK_HIP_TRY(hipMemsetAsync(b, 0, w.total, stream));
 
-    const uint32_t hgrid = w.tiles < 2048u ? (w.tiles ? w.tiles : 1u) : 2048u;
+    // every workgroup ends with up to 1024 atomics on the same 1024 words: few, long-running workgroups
+    const uint32_t hgrid = w.tiles < 512u ? (w.tiles ? w.tiles : 1u) : 512u;
     histogram_kernel<<<hgrid, THREADS, 0, stream>>>(keysA, n, ghist);
     KK_LAUNCH_CHECK();
 
