@@ -192,23 +192,37 @@ __global__ __launch_bounds__(THREADS) void onesweep_pass_kernel(
             st_status(row, total | FLAG_INC);
         } else {
             st_status(row, total | FLAG_AGG);
+            // look back over the predecessors, LOOK of them per round trip to memory: their words are
+            // read together and used in order, up to the first that is not published yet
+            constexpr uint32_t LOOK = 4;
             uint32_t t = tile - 1;
             uint32_t spins = 0;
-            while (true) {
-                const uint32_t s = ld_status(tileStatus + static_cast<size_t>(t) * RADIX + d);
-                const uint32_t f = s & FLAG_MASK;
-                if (f == 0) {
-                    if (++spins > SPIN_LIMIT) {
-                        atomicOr(errorFlag, 1u);
+            bool done = false;
+            while (!done) {
+                uint32_t s[LOOK];
+#pragma unroll
+                for (uint32_t u = 0; u < LOOK; ++u)
+                    s[u] = u <= t ? ld_status(tileStatus + static_cast<size_t>(t - u) * RADIX + d) : 0u;
+#pragma unroll
+                for (uint32_t u = 0; u < LOOK; ++u) {
+                    const uint32_t f = s[u] & FLAG_MASK;
+                    if (f == 0) { // tile t not there yet: read again from it
+                        if (u == 0) {
+                            if (++spins > SPIN_LIMIT) {
+                                atomicOr(errorFlag, 1u);
+                                done = true;
+                            } else
+                                __builtin_amdgcn_s_sleep(2);
+                        }
                         break;
                     }
-                    __builtin_amdgcn_s_sleep(2);
-                    continue;
+                    exclusive += s[u] & VALUE_MASK;
+                    if (f == FLAG_INC || t == 0) {
+                        done = true;
+                        break;
+                    }
+                    --t;
                 }
-                exclusive += s & VALUE_MASK;
-                if (f == FLAG_INC || t == 0)
-                    break;
-                --t;
             }
             st_status(row, ((exclusive + total) & VALUE_MASK) | FLAG_INC);
         }
