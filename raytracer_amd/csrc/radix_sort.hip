@@ -171,27 +171,38 @@ __global__ __launch_bounds__(THREADS) void onesweep_pass_kernel(
     }
     __syncthreads();
 
-    // 3. thread d owns digit d
+    // 3. thread d owns digit d: its count in this tile goes out at once (the tiles behind wait for it)
+    const int dg = tid;
+    uint32_t total = 0, dstart, gstart;
+    uint32_t *row = tileStatus + static_cast<size_t>(tile) * RADIX + dg;
     {
-        const int d = tid;
         uint32_t c[WAVES];
-        uint32_t total = 0;
 #pragma unroll
         for (int w = 0; w < WAVES; ++w) {
-            c[w] = s_whist[w][d];
-            s_whist[w][d] = total; // exclusive over waves
+            c[w] = s_whist[w][dg];
+            s_whist[w][dg] = total; // exclusive over waves
             total += c[w];
         }
-        const uint32_t dstart = block_exclusive_scan(total, s_tmp, tid);
-        const uint32_t gstart = block_exclusive_scan(ghist[d], s_tmp, tid);
-        s_digitStart[d] = dstart;
+        st_status(row, total | (tile == 0 ? FLAG_INC : FLAG_AGG));
+        dstart = block_exclusive_scan(total, s_tmp, tid);
+        gstart = block_exclusive_scan(ghist[dg], s_tmp, tid);
+        s_digitStart[dg] = dstart;
+    }
+    __syncthreads();
 
-        uint32_t *row = tileStatus + static_cast<size_t>(tile) * RADIX + d;
+    // 4. scatter into LDS in tile-sorted order; the tiles in front publish meanwhile
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const uint32_t d = (key[i] >> shift) & 255u;
+        const uint32_t p = s_digitStart[d] + s_whist[wave][d] + rank[i];
+        s_keys[p] = key[i];
+        s_vals[p] = val[i];
+    }
+
+    // 5. where the digit starts in the output: the counts of all tiles in front
+    {
         uint32_t exclusive = 0;
-        if (tile == 0) {
-            st_status(row, total | FLAG_INC);
-        } else {
-            st_status(row, total | FLAG_AGG);
+        if (tile != 0) {
             // look back over the predecessors, LOOK of them per round trip to memory: their words are
             // read together and used in order, up to the first that is not published yet
             constexpr uint32_t LOOK = 4;
@@ -202,7 +213,7 @@ __global__ __launch_bounds__(THREADS) void onesweep_pass_kernel(
                 uint32_t s[LOOK];
 #pragma unroll
                 for (uint32_t u = 0; u < LOOK; ++u)
-                    s[u] = u <= t ? ld_status(tileStatus + static_cast<size_t>(t - u) * RADIX + d) : 0u;
+                    s[u] = u <= t ? ld_status(tileStatus + static_cast<size_t>(t - u) * RADIX + dg) : 0u;
 #pragma unroll
                 for (uint32_t u = 0; u < LOOK; ++u) {
                     const uint32_t f = s[u] & FLAG_MASK;
@@ -226,19 +237,11 @@ __global__ __launch_bounds__(THREADS) void onesweep_pass_kernel(
             }
             st_status(row, ((exclusive + total) & VALUE_MASK) | FLAG_INC);
         }
-        s_globalBase[d] = gstart + exclusive - dstart;
+        s_globalBase[dg] = gstart + exclusive - dstart;
     }
     __syncthreads();
 
-    // 4. scatter into LDS in tile-sorted order, then stream out
-#pragma unroll
-    for (int i = 0; i < ITEMS; ++i) {
-        const uint32_t d = (key[i] >> shift) & 255u;
-        const uint32_t p = s_digitStart[d] + s_whist[wave][d] + rank[i];
-        s_keys[p] = key[i];
-        s_vals[p] = val[i];
-    }
-    __syncthreads();
+    // 6. stream out
     const uint32_t remaining = n - tileBase;
     const uint32_t validCount = remaining < static_cast<uint32_t>(TILE) ? remaining : TILE;
     for (uint32_t j = tid; j < validCount; j += THREADS) {
