@@ -112,9 +112,25 @@ int kk_lbvh_build(const float *d_positions, uint32_t vert_num, const uint32_t *d
  * payload = index), as lbvh.cu:110,172 uses thrust::sequence + sort_by_key. Result lands in
  * d_keys_a / d_vals_a; the *_b arrays and d_workspace (kk_sort_workspace_bytes) are scratch. */
 size_t kk_sort_workspace_bytes(uint32_t n);
+/* Byte offset inside d_workspace of a uint32 that is non-zero after the sort when a tile's look-back
+ * gave up waiting for its predecessor (the output is then not sorted): read it back after
+ * synchronising when the result must be trusted. d_keys_a must be 16-byte aligned. */
+size_t kk_sort_workspace_error_offset(uint32_t n);
 int kk_sort_pairs_u32(uint32_t *d_keys_a, uint32_t *d_keys_b, uint32_t *d_vals_a, uint32_t *d_vals_b,
                       int vals_are_iota, uint32_t n, void *d_workspace, size_t workspace_bytes,
                       void *stream);
+
+/* The same sort for callers that cannot allocate device memory (code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc). No counterpart in the reference. It takes no
+ * workspace: the histograms, tile counters and look-back rows live in a device array that is part of
+ * the library image, sized for n <= KK_SORT_STATIC_MAX_N (about 4.2 MB, held by every GPU the library
+ * runs on until the process ends). Larger n is rejected with KK_ERR_INVALID. The call allocates
+ * nothing and frees nothing; it clears the part of the array it uses on `stream` first. All calls on
+ * one GPU share that array: calls that overlap in time on one GPU (different streams or threads) race.
+ * Result as kk_sort_pairs_u32: in d_keys_a / d_vals_a. d_keys_a must be 16-byte aligned. */
+#define KK_SORT_STATIC_MAX_N (1u << 22)
+int kk_sort_pairs_u32_static(uint32_t *d_keys_a, uint32_t *d_keys_b, uint32_t *d_vals_a,
+                             uint32_t *d_vals_b, int vals_are_iota, uint32_t n, void *stream);
 
 /* ================================================================================================
  * Path 1b: closest hit  --  rayCastLBVH<false> (src/ray_tracer/ray_tracer_render.cu:192-270)

@@ -87,6 +87,9 @@ def _declare(l):
     l.kk_sort_workspace_bytes.restype = sz
     l.kk_sort_workspace_bytes.argtypes = [u32]
     l.kk_sort_pairs_u32.argtypes = [vp, vp, vp, vp, i32, u32, vp, sz, vp]
+    l.kk_sort_workspace_error_offset.restype = sz
+    l.kk_sort_workspace_error_offset.argtypes = [u32]
+    l.kk_sort_pairs_u32_static.argtypes = [vp, vp, vp, vp, i32, u32, vp]
     l.kk_lbvh_workspace_layout.argtypes = [u32, u32, u32, C.POINTER(LbvhWsLayout)]
     l.kk_lbvh_build.argtypes = [vp, u32, vp, u32, vp, vp, vp, vp, vp, sz, u32, vp]
     l.kk_closest_hit_workspace_bytes.restype = sz

@@ -16,6 +16,8 @@
 // HBM traffic per key: 4 B (histogram) + 4 x (8 B read + 8 B write) = 68 B.
 #include "kk_host.h"
 
+#include <mutex>
+
 namespace kk {
 namespace rsort {
 
@@ -320,12 +322,72 @@ int sort_pairs(uint32_t *keysA, uint32_t *keysB, uint32_t *valsA, uint32_t *vals
 } // namespace kk
 
 extern "C" size_t kk_sort_workspace_bytes(uint32_t n) { return kk::rsort::sort_ws(n).total; }
+extern "C" size_t kk_sort_workspace_error_offset(uint32_t n) { return kk::rsort::sort_ws(n).error; }
+
+// ---- the sort for callers that cannot allocate --------------------------------------------------------
+// The sort's scratch (digit histograms, tile counters, error word, look-back status rows) in a
+// file-scope device array instead of a caller's workspace. Each GPU holds its own copy at its own
+// address: the address is asked for once per device and kept; host code only ever uses that pointer.
+namespace kk {
+namespace rsort {
+
+constexpr size_t static_scratch_bytes(uint32_t n) {
+    // what sort_ws() carves: ghist, counters and error word (one 256-byte aligned piece each), then
+    // the status rows of all passes
+    const size_t tiles = (static_cast<size_t>(n) + TILE - 1) / TILE;
+    return sizeof(uint32_t) * PASSES * RADIX + 256 + 256 + sizeof(uint32_t) * PASSES * tiles * RADIX;
+}
+constexpr size_t STATIC_SCRATCH_BYTES = static_scratch_bytes(KK_SORT_STATIC_MAX_N);
+static __device__ __align__(256) unsigned char scratch[STATIC_SCRATCH_BYTES];
+
+constexpr int MAX_DEVICES = 64;
+static std::mutex g_scratchMutex;
+static void *g_scratchPtr[MAX_DEVICES] = {};
+
+// Device address of this GPU's copy of `scratch`, looked up on the first call per device.
+static int scratch_ptr(void **out) {
+    int dev = -1;
+    KK_HIP_TRY(hipGetDevice(&dev));
+    KK_REQUIRE(dev >= 0 && dev < MAX_DEVICES, "device index out of range");
+    std::lock_guard<std::mutex> lock(g_scratchMutex);
+    if (!g_scratchPtr[dev]) {
+        void *p = nullptr;
+        KK_HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        KK_REQUIRE(p != nullptr, "no device address for the static scratch");
+        g_scratchPtr[dev] = p;
+    }
+    *out = g_scratchPtr[dev];
+    return KK_OK;
+}
+
+} // namespace rsort
+} // namespace kk
+
+extern "C" int kk_sort_pairs_u32_static(uint32_t *d_keys_a, uint32_t *d_keys_b, uint32_t *d_vals_a,
+                                        uint32_t *d_vals_b, int vals_are_iota, uint32_t n,
+                                        void *stream) {
+    using namespace kk::rsort;
+    KK_REQUIRE(d_keys_a && d_keys_b && d_vals_a && d_vals_b, "null pointer");
+    KK_REQUIRE(n > 0, "n out of range");
+    KK_REQUIRE(n <= KK_SORT_STATIC_MAX_N,
+               "n exceeds KK_SORT_STATIC_MAX_N, the size the static scratch is made for");
+    KK_REQUIRE((reinterpret_cast<uintptr_t>(d_keys_a) & 15u) == 0, "d_keys_a must be 16-byte aligned");
+    KK_REQUIRE(sort_ws(n).total <= STATIC_SCRATCH_BYTES, "static scratch too small");
+    void *ws = nullptr;
+    const int rc = scratch_ptr(&ws);
+    if (rc != KK_OK)
+        return rc;
+    // sort_pairs clears the part of the scratch it uses (histograms, counters, status rows) first
+    return sort_pairs(d_keys_a, d_keys_b, d_vals_a, d_vals_b, vals_are_iota != 0, n, ws,
+                      STATIC_SCRATCH_BYTES, static_cast<hipStream_t>(stream), nullptr, PASSES);
+}
 
 extern "C" int kk_sort_pairs_u32(uint32_t *d_keys_a, uint32_t *d_keys_b, uint32_t *d_vals_a,
                                  uint32_t *d_vals_b, int vals_are_iota, uint32_t n,
                                  void *d_workspace, size_t workspace_bytes, void *stream) {
     KK_REQUIRE(d_keys_a && d_keys_b && d_vals_a && d_vals_b && d_workspace, "null pointer");
     KK_REQUIRE(n > 0 && n <= KK_LBVH_MAX_FACES, "n out of range");
+    KK_REQUIRE((reinterpret_cast<uintptr_t>(d_keys_a) & 15u) == 0, "d_keys_a must be 16-byte aligned");
     return kk::rsort::sort_pairs(d_keys_a, d_keys_b, d_vals_a, d_vals_b, vals_are_iota != 0, n,
                                  d_workspace, workspace_bytes, static_cast<hipStream_t>(stream),
                                  nullptr, kk::rsort::PASSES);
