@@ -1,0 +1,92 @@
+"""Parity at the benchmark's full sizes, through the C ABI, against the CPU checker.
+
+Kingsnake shape (1024 x 1024 x 795 uint8, README Kingsnake transfer function, log2Dims {5,4,3}, depth
+boxes on) at 3840 x 2160: the VDB's parameters, pools, atlas map and atlas bit for bit, and a 24-row band
+of the frame at two angles of the reference's orbit (ray_caster_dpbx_vdb.cu:439-532; opacity exact,
+colour within one 8-bit level on at most 1 % of the pixels, see test_gpu_dvr.py).
+
+10 M-triangle soup: the tree's arrays byte for byte, and 262,144 of the benchmark's 2,097,152 rays
+against the checker's walk in the reference's order (ray_tracer_render.cu:192-270): the same primitive
+for every ray but a stated 1e-4 (equal-distance ties), and identical bits of t and the barycentrics."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+from raytracer_amd import synthetic as syn  # noqa: E402
+from raytracer_amd.data import camera as cam  # noqa: E402
+from raytracer_amd.dpbx_vdb import DepthBoxVDB, Volume  # noqa: E402
+from raytracer_amd.lbvh import LBVH  # noqa: E402
+from raytracer_amd.ray_caster import FrameBuffer, RayCaster, TransferFunctionTable  # noqa: E402
+from raytracer_amd.ray_tracer import closest_hit  # noqa: E402
+from test_gpu_dvr import _check_images, _compare_build  # noqa: E402
+from vol_util import SNAKE_TF, dvr_setup  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def test_kingsnake_4k_build_and_frame_bands(oracle):
+    dim = (1024, 1024, 795)
+    W, H = 3840, 2160
+    vol_t = syn.kingsnake_volume_torch(dim, DEV)
+    vdb = DepthBoxVDB(DEV)
+    vdb.BuildFrom(Volume(vol_t, DEV), SNAKE_TF.empty_scalar_ranges, apron_wid=1, log2_dims=(5, 4, 3),
+                  use_depth_box=True)
+    assert vdb.IsComplete()
+    ref = oracle.OracleVDB(vol_t.cpu().numpy(), (5, 4, 3), 1, True, SNAKE_TF.empty_scalar_ranges)
+    del vol_t
+    _compare_build(vdb, ref)
+    p = vdb.plan.param
+    assert p.root_lev == 2 and p.vox_per_vdb == 4096.0 and p.vox_per_atlas_brick == 36
+    assert tuple(vdb.plan.leaf_slots) == (32, 32, 25) and 1000 < vdb.plan.leaf_num < 4000
+
+    caster = RayCaster(DEV)
+    caster.SetDepthBoxVDB(vdb)
+    caster.SetTransferFunctionTexture(TransferFunctionTable(SNAKE_TF.dat, DEV))
+    fb = FrameBuffer(W, H, DEV)
+    for orbit, y0 in ((8, H // 2 - 12), (193, 700)):  # the bench's first timed pose; a quarter turn on
+        w2s, c, proj = dvr_setup(dim, (1, 1, 1), W, H, orbit_steps=orbit)
+        caster.SetWorldToScene(w2s)
+        caster.SetProjection(proj)
+        caster.SetCameraToWorld(c.pos, c.rotation())
+        caster.RenderDepthBoxVDB(fb)
+        torch.cuda.synchronize()
+        got = fb.ReadBack()[y0:y0 + 24]
+        want = np.zeros((H, W, 4), np.uint8)
+        _, ns = oracle.dvr_render(ref, SNAKE_TF.dat, w2s, cam.inverse_projective(proj), c.pos,
+                                  c.rotation(), W, H, rows=(y0, y0 + 24), rgba=want)
+        assert ns > 100_000, "the band must cross the tube"
+        _check_images(got, want[y0:y0 + 24])
+        assert got[..., 3].max() > 200
+
+
+def test_ten_million_triangles_tree_and_262144_rays(oracle):
+    n, rays_total, sample = 10_000_000, 2_097_152, 262_144
+    pos, tri = syn.triangle_soup(n)
+    bvh = LBVH(DEV)
+    bvh.BuildFrom(torch.from_numpy(pos), torch.from_numpy(tri.view(np.int32)))
+    assert bvh.IsComplete()
+    ref = oracle.lbvh_build(pos, tri, refit_mode=1)
+    M = bvh.GetDeviceData()["compactedFaceNum"]
+    assert M == ref["M"] and 0.99 * n < M <= n
+    assert bvh.d_faces.cpu().numpy().view(np.uint32).tobytes() == ref["faces"].tobytes()
+    assert bvh.d_compacted[:M].cpu().numpy().view(np.uint32).tobytes() == ref["compactedFaces"].tobytes()
+    assert bvh.d_nodes[:(M - 1) * 32].cpu().numpy().tobytes() == ref["internalNodes"].tobytes()
+    np.testing.assert_array_equal(bvh.GetDeviceData()["rootAABB"], ref["rootAABB"].reshape(-1))
+
+    # rays spread over the whole stream: every eighth ray of the 2,097,152
+    rays = syn.incoherent_rays(rays_total)[::rays_total // sample].copy()
+    assert rays.shape[0] == sample
+    t, bary, prim = [x.cpu().numpy() for x in closest_hit(bvh, rays)]
+    prim = prim.view(np.uint32)
+    rt, rbary, rprim, _ = oracle.closest_hit(ref, pos, tri, rays)
+    mism = prim != rprim
+    assert float(mism.mean()) <= 1e-4, float(mism.mean())
+    ok = ~mism
+    assert t[ok].tobytes() == rt[ok].tobytes()
+    hit = ok & (rprim != 0xFFFFFFFF)
+    assert bary[hit].tobytes() == rbary[hit].tobytes()
+    if mism.any():
+        np.testing.assert_allclose(t[mism], rt[mism], rtol=1e-5)
+    assert 0.3 < float(hit.mean()) <= 1.0
