@@ -292,6 +292,12 @@ int kk_pt_render_sample(const kk_lbvh_device_data *d_lbvh, const kk_pt_scene *h_
                         const kk_pt_frame *h_frame, float *d_accum, uint8_t *d_rgba, int width,
                         int height, int y0, int y1, float sample_index, uint32_t seed, void *stream);
 
+/* Diagnostics of the path-tracing kernel on the trace-side tree: while d_counters (uint64[16], zeroed by
+ * the caller) is set, every kk_pt_render_sample adds [0] passes of the waves' walk loop, [1] lanes that
+ * walked in them, [2] shade phases, [3] lanes that waited at their start, [4] rays (closest-hit and
+ * shadow), [5] node records visited, [6] triangles tested. NULL switches it off (the default). */
+int kk_pt_set_work_counters(unsigned long long *d_counters);
+
 /* The other targets of RayTracer::Render (ray_tracer.h RenderTarget; ray_tracer_render.cu:461-558):
  * one frame of rows [y0, y1) straight into d_rgba, no accumulation. AABBs draws the boxes at tree depth
  * h_scene->display_tree_height (:8-100); Triangles / Positions / Normals / TextureCoords shade the

@@ -1,6 +1,7 @@
 // Error string, build info and the small memory/stream helpers of the C ABI.
 #include "kk_host.h"
 
+#include <atomic>
 #include <stdarg.h>
 #include <string.h>
 
@@ -11,6 +12,20 @@ void set_error(const char *fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(g_error, sizeof(g_error), fmt, ap);
     va_end(ap);
+}
+int device_cu_count() {
+    constexpr int MAX_DEVICES = 64;
+    static std::atomic<int> cached[MAX_DEVICES] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES)
+        return 256;
+    int n = cached[dev].load(std::memory_order_relaxed);
+    if (n == 0) {
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+            n = 256;
+        cached[dev].store(n, std::memory_order_relaxed);
+    }
+    return n;
 }
 } // namespace kk
 

@@ -39,6 +39,9 @@ void set_error(const char *fmt, ...);
         }                                                                                          \
     } while (0)
 
+// Compute units of the current device (asked once per device); 256 when the query fails.
+int device_cu_count();
+
 inline uint32_t div_up(uint64_t a, uint64_t b) { return static_cast<uint32_t>((a + b - 1) / b); }
 inline size_t align_up(size_t a, size_t b = 256) { return (a + b - 1) / b * b; }
 

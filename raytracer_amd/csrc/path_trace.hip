@@ -15,6 +15,9 @@
 #include "traverse.h"
 #include "wide_walk.h"
 
+#include <atomic>
+#include <mutex>
+
 namespace kk {
 namespace pt {
 
@@ -342,6 +345,528 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(5, 5)))
     reinterpret_cast<uchar4 *>(rgba)[idx] = o;
 }
 
+// ---- the frame as a persistent, compacting kernel (8-wide tree) ----------------------------------------
+//
+// One lane per pixel and launch leaves a wave waiting for its longest path while the lanes of finished
+// paths idle. Here a grid of resident wave64 workgroups pulls pixels from a queue (8 x 8 pixel tiles in
+// row-major tile order) and every lane is a small state machine over the rays of its path:
+//   walking a closest-hit ray | walking a shadow ray | walk over, to be shaded | idle.
+// The wave alternates between two phases. Walk: every lane with a ray does one step per pass (visit
+// one record, or test one triangle of the last visit's run), the per-lane sequence of closest_hit_lane /
+// occluded_lane; a run of COOP_MIN or more triangles is tested by the whole wave for the lane that owns
+// it, so one long leaf does not hold 63 lanes up. Shade: when no lane walks any more, every lane
+// consumes its walk's result (hit -> material, normal; shadow answer -> add the light), samples lights
+// until one needs a shadow ray, or samples the path's next direction, and lanes whose path ended write
+// their pixel and take the next pixels of the queue with one ballot + one atomic per wave - so each
+// section of the shading code runs once per phase with every lane that needs it. A lane computes its
+// path with the same operations in the same order as renderScene above, and the random stream is keyed
+// by (pixel, sample, draw), so the image does not depend on the scheduling.
+namespace persist {
+
+enum : uint32_t {
+    ST_IDLE = 0,       // no pixel (queue used up)
+    ST_WALK_C = 1,     // walking a closest-hit ray
+    ST_WALK_S = 2,     // walking a shadow ray
+    ST_DONE_C = 3,     // closest-hit walk over: best holds the hit
+    ST_DONE_S_HIT = 4, // shadow ray blocked
+    ST_DONE_S_CLEAR = 5,
+    ST_LIGHTS = 6, // choosing the next light that needs a shadow ray, or the path's next direction
+    ST_END = 7     // path over: pixel to be written
+};
+
+#ifndef KK_PT_WAVES
+#define KK_PT_WAVES 4 // resident waves per SIMD = workgroups per CU
+#endif
+constexpr int WALK_FIRST = 1;  // leave the walk loop for shading once fewer lanes than this walk while others wait
+constexpr int COOP_MIN = 8;    // a leaf run of at least this many triangles is tested by the whole wave
+constexpr uint32_t COUNTER_SLOTS = 64;
+// Queue heads of the launches in flight: a launch takes the next slot and clears it on its stream
+// first. (Launches more than COUNTER_SLOTS apart share a slot; they cannot overlap unless that many
+// are in flight on one GPU at once.)
+static __device__ uint32_t g_pixelQueue[COUNTER_SLOTS * 32];
+
+// The acceptance test of a walk's final hit (see trace_accel.hip): the ray must pass the reference's slab
+// test of the box of the hit triangle's leaf's parent. The triangle's own box lies inside that box and
+// the test is monotonic in the box, so a pass there settles it without loading the parent node.
+__device__ __forceinline__ bool final_hit_passes(const kk_lbvh_node *__restrict__ nodes,
+                                                 const accel::TriRec *__restrict__ recs, uint32_t w,
+                                                 const accel::RayState &ray) {
+    const uint4 *tp = reinterpret_cast<const uint4 *>(recs + w);
+    const uint4 a = tp[0], b = tp[1], c = tp[2];
+    const f3 v0 = F3(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z));
+    const f3 v1 = F3(__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z));
+    const f3 v2 = F3(__uint_as_float(c.x), __uint_as_float(c.y), __uint_as_float(c.z));
+    AABB tb;
+    tb.minPos = {fminf(fminf(v0.x, v1.x), v2.x), fminf(fminf(v0.y, v1.y), v2.y), fminf(fminf(v0.z, v1.z), v2.z)};
+    tb.maxPos = {fmaxf(fmaxf(v0.x, v1.x), v2.x), fmaxf(fmaxf(v0.y, v1.y), v2.y), fmaxf(fmaxf(v0.z, v1.z), v2.z)};
+    if (accel::passes_box(tb, ray))
+        return true;
+    return accel::passes_parent(nodes, b.w, ray);
+}
+
+struct PathState {
+    // the path
+    uint32_t pixel;  // y * W + x
+    uint32_t draw;   // random numbers drawn so far
+    uint32_t depth;  // bounce
+    uint32_t li;     // light being sampled
+    uint32_t grp;    // material of the last hit
+    float fOverPdf;  // geometric factor / pdf of the light sample whose shadow ray is out
+    f3 throughout, Lo, Li, norm, dirOut;
+};
+
+} // namespace persist
+
+template <bool COUNT>
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(KK_PT_WAVES, KK_PT_WAVES))) void path_trace_persistent_kernel(
+    const accel::View view, const kk_pt_scene p, const kk_pt_frame f, float *__restrict__ accum,
+    uint8_t *__restrict__ rgba, int W, int H, int y0, int y1, float sampleIdx, uint32_t seed,
+    uint32_t *pixelQueue, unsigned long long *counters, int walkFirst, int coopMin) {
+    using namespace persist;
+    using namespace accel;
+    __shared__ uint32_t s_stack[LANE_LDS_DEPTH * THREADS];
+    __shared__ unsigned short s_bits[LANE_LDS_DEPTH * THREADS];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const unsigned long long lanesBelow = (1ull << lane) - 1ull;
+    const LaneStack st{s_stack + tid, s_bits + tid, THREADS};
+    uint2 deep[LANE_DEPTH - LANE_LDS_DEPTH];
+
+    const kk_lbvh_node *nodes = view.hdr->nodes;
+    const char *wideBytes = reinterpret_cast<const char *>(view.wide);
+    AABB rootBox;
+    rootBox.minPos = {view.hdr->rootBox[0], view.hdr->rootBox[1], view.hdr->rootBox[2]};
+    rootBox.maxPos = {view.hdr->rootBox[3], view.hdr->rootBox[4], view.hdr->rootBox[5]};
+
+    const uint32_t tilesX = (static_cast<uint32_t>(W) + 7u) >> 3;
+    const uint32_t tilesY = (static_cast<uint32_t>(y1 - y0) + 7u) >> 3;
+    const uint32_t queueLen = tilesX * tilesY * 64u;
+    const uint32_t sample = static_cast<uint32_t>(sampleIdx);
+    constexpr float RR = .8f;
+
+    uint32_t stage = ST_IDLE;
+    bool poolEmpty = false;
+    PathState ps{};
+    RayState ray{};
+    RaySigns sg{false, false, false, 0u};
+    uint32_t mode = MODE_FAST;
+    LaneWalk w{};
+    uint32_t pendW = 0u, pendC = 0u;
+    Hit8 best{};
+
+    unsigned long long cntPasses = 0, cntWalkLanes = 0, cntShades = 0, cntShadeLanes = 0, cntRays = 0,
+                       cntVisits = 0, cntTris = 0;
+    // a new ray for this lane: `closest` walks for the nearest hit, else for any hit nearer than tMax
+    auto start_ray = [&](f3 pos, f3 dir, bool closest, float tMax) {
+        if (COUNT)
+            ++cntRays;
+        best.t = closest ? FloatMax : tMax;
+        best.bx = best.by = 0.f;
+        best.fi = best.k = best.w = 0xFFFFFFFFu;
+        best.sure = false;
+        pendC = 0u;
+        float tEnter, tExit;
+        HitAABB(Ray{pos, dir}, rootBox, tEnter, tExit);
+        prepare_ray(pos, dir, ray, sg, mode);
+        if (!closest && mode == MODE_FAST)
+            mode = MODE_CAREFUL; // a shadow ray checks every candidate as it meets it
+        w.start(sg.oct);
+        if (tEnter > tExit)
+            stage = closest ? ST_DONE_C : ST_DONE_S_CLEAR;
+        else
+            stage = closest ? ST_WALK_C : ST_WALK_S;
+    };
+
+    // What a finished walk means for its path; run at the head of the sections that follow walks.
+    auto consume_walk = [&]() {
+        // a closest-hit walk is over (ray_tracer_render.cu:321-347)
+        if (stage == ST_DONE_C) {
+            if (best.t == FloatMax)
+                stage = ST_END;
+            else {
+                const kk_pt_triangle triangle = p.triangles[best.fi];
+                ps.grp = triangle.grp_idx;
+                const kk_material &matr = p.materials[ps.grp];
+                if (matr.emissive) {
+                    ps.Lo = ps.Lo + ps.throughout * V(matr.emission);
+                    stage = ST_END;
+                } else {
+                    ps.norm = normalize(best.bx * trav::load_pos(p.normals, triangle.norm_idx[0]) +
+                                        best.by * trav::load_pos(p.normals, triangle.norm_idx[1]) +
+                                        (1.f - best.bx - best.by) *
+                                            trav::load_pos(p.normals, triangle.norm_idx[2]));
+                    ps.dirOut = -ray.dir;
+                    ray.pos = ray.pos + best.t * ray.dir + Eps * ps.norm;
+                    ps.Li = F3(0.f);
+                    ps.li = 0u;
+                    stage = ST_LIGHTS;
+                }
+            }
+        }
+        // a shadow walk is over (:381-389)
+        if (stage == ST_DONE_S_CLEAR) {
+            const kk_material matr = p.materials[ps.grp];
+            const kk_light &lht = p.lights[ps.li];
+            ps.Li = ps.Li + ps.fOverPdf * V(lht.radiance) * BRDF(matr, ray.dir, ps.dirOut, ps.norm);
+        }
+        if (stage == ST_DONE_S_HIT || stage == ST_DONE_S_CLEAR) {
+            ++ps.li;
+            stage = ST_LIGHTS;
+        }
+
+    };
+    long long tcLoop = 0, tcV = 0, tcT = 0, tcCoop = 0, tcLights = 0, tcBounce = 0, tcEnd = 0, tc0 = 0, tc1 = 0;
+    auto lap = [&](long long &acc) {
+        if (COUNT) {
+            tc1 = clock64();
+            acc += tc1 - tc0;
+            tc0 = tc1;
+        }
+    };
+    if (COUNT)
+        tc0 = clock64();
+    while (true) {
+        // ================= walk: one step per lane and pass until no lane has a ray ====================
+        while (true) {
+            const int nWalk = __popcll(__ballot(stage == ST_WALK_C || stage == ST_WALK_S));
+            // leave when no lane walks, or when few still do while others wait to be shaded
+            if (nWalk == 0 || (nWalk < walkFirst && __ballot(stage >= ST_DONE_C || (stage == ST_IDLE && !poolEmpty)) != 0ull))
+                break;
+            if (COUNT) {
+                ++cntPasses;
+                cntWalkLanes += nWalk;
+            }
+            lap(tcLoop);
+            if (stage == ST_WALK_C || stage == ST_WALK_S) {
+                if (pendC == 0u) {
+                    uint32_t cur;
+                    if (!w.next(st, deep, sg.oct, cur)) {
+                        if (stage == ST_WALK_S)
+                            stage = ST_DONE_S_CLEAR;
+                        else if (best.fi != 0xFFFFFFFFu && mode == MODE_FAST &&
+                                 !final_hit_passes(nodes, view.recs, best.w, ray)) {
+                            // the final hit fails its parent-box test: walk again, checking every hit
+                            mode = MODE_CAREFUL;
+                            best.t = FloatMax;
+                            best.bx = best.by = 0.f;
+                            best.fi = best.k = best.w = 0xFFFFFFFFu;
+                            w.start(sg.oct);
+                        } else
+                            stage = ST_DONE_C;
+                    } else {
+                        const float limit = best.t + trav::CULL_SLACK * best.t;
+                        bool unusedFlag = false;
+                        const Visit vis = visit_record<false>(wideBytes, cur, ray, sg, limit, unusedFlag);
+                        pendW = vis.leafW;
+                        pendC = vis.leafC;
+                        w.enter(st, deep, vis, sg.oct);
+                        if (COUNT)
+                            ++cntVisits;
+                    }
+                }
+                lap(tcV);
+                if (pendC != 0u && pendC < static_cast<uint32_t>(coopMin) &&
+                    (stage == ST_WALK_C || stage == ST_WALK_S)) {
+                    if (COUNT)
+                        ++cntTris;
+                    const uint4 *tp = reinterpret_cast<const uint4 *>(view.recs + pendW);
+                    const uint4 a = tp[0], b = tp[1], c = tp[2];
+                    const f3 v0 = F3(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z));
+                    const f3 v1 = F3(__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z));
+                    const f3 v2 = F3(__uint_as_float(c.x), __uint_as_float(c.y), __uint_as_float(c.z));
+                    float bx = 0.f, by = 0.f;
+                    const float t = HitTriangle(Ray{ray.pos, ray.dir}, v0, v1, v2, bx, by);
+                    const bool isClosest = stage == ST_WALK_C;
+                    if (t >= 0.f && (t < best.t || (isClosest && t == best.t && c.w < best.k))) {
+                        if (mode == MODE_FAST || (mode == MODE_CAREFUL ? passes_parent(nodes, b.w, ray)
+                                                                       : passes_chain(nodes, view.parents, b.w, ray))) {
+                            if (isClosest) {
+                                best.t = t;
+                                best.bx = bx;
+                                best.by = by;
+                                best.fi = a.w;
+                                best.k = c.w;
+                                best.w = pendW;
+                            } else
+                                stage = ST_DONE_S_HIT;
+                        }
+                    }
+                    ++pendW;
+                    --pendC;
+                }
+            }
+            lap(tcT);
+            // A long run of triangles (a leaf of many faces with one Morton code) would keep its lane
+            // walking long after the others: the whole wave tests it, 64 triangles at a time, for the
+            // lane that owns it. The owner ends up with the hit its own one-by-one loop would keep: the
+            // smallest (t, sorted position) among the triangles that are hit and accepted.
+            unsigned long long coop = __ballot((stage == ST_WALK_C || stage == ST_WALK_S) &&
+                                               pendC >= static_cast<uint32_t>(coopMin));
+            while (coop != 0ull) {
+                const int o = __ffsll(static_cast<long long>(coop)) - 1;
+                auto bcF = [&](float v) { return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), o)); };
+                auto bcU = [&](uint32_t v) { return static_cast<uint32_t>(__builtin_amdgcn_readlane(v, o)); };
+                RayState oray;
+                oray.pos = F3(bcF(ray.pos.x), bcF(ray.pos.y), bcF(ray.pos.z));
+                oray.dir = F3(bcF(ray.dir.x), bcF(ray.dir.y), bcF(ray.dir.z));
+                oray.inv = F3(bcF(ray.inv.x), bcF(ray.inv.y), bcF(ray.inv.z));
+                const uint32_t oW = bcU(pendW), oC = bcU(pendC), oMode = bcU(mode);
+                const bool oClosest = bcU(stage) == ST_WALK_C;
+                const float oT = bcF(best.t);
+                const uint32_t oK = bcU(best.k);
+                const uint32_t n = oC < 64u ? oC : 64u;
+                bool cand = false;
+                float t = 0.f, bx = 0.f, by = 0.f;
+                uint32_t fi = 0u, k = 0u;
+                if (static_cast<uint32_t>(lane) < n) {
+                    const uint4 *tp = reinterpret_cast<const uint4 *>(view.recs + oW + lane);
+                    const uint4 a = tp[0], b = tp[1], c = tp[2];
+                    const f3 v0 = F3(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z));
+                    const f3 v1 = F3(__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z));
+                    const f3 v2 = F3(__uint_as_float(c.x), __uint_as_float(c.y), __uint_as_float(c.z));
+                    t = HitTriangle(Ray{oray.pos, oray.dir}, v0, v1, v2, bx, by);
+                    fi = a.w;
+                    k = c.w;
+                    cand = t >= 0.f && (t < oT || (oClosest && t == oT && k < oK));
+                    if (cand && oMode != MODE_FAST)
+                        cand = oMode == MODE_CAREFUL ? passes_parent(nodes, b.w, oray)
+                                                     : passes_chain(nodes, view.parents, b.w, oray);
+                }
+                if (COUNT && lane == o)
+                    cntTris += n;
+                const unsigned long long cm = __ballot(cand);
+                if (cm != 0ull) {
+                    if (!oClosest) {
+                        if (lane == o)
+                            stage = ST_DONE_S_HIT;
+                    } else {
+                        // t >= 0: its bits order like the value ("+ 0" turns -0 into +0)
+                        unsigned long long key =
+                            cand ? (static_cast<unsigned long long>(__float_as_uint(t + 0.f)) << 32) | k : ~0ull;
+                        unsigned long long m = key;
+                        for (int off = 32; off > 0; off >>= 1) {
+                            const unsigned long long other = __shfl_xor(m, off, 64);
+                            m = other < m ? other : m;
+                        }
+                        const int win = __ffsll(static_cast<long long>(__ballot(cand && key == m))) - 1;
+                        const float wt = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(t), win));
+                        const float wbx = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(bx), win));
+                        const float wby = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(by), win));
+                        const uint32_t wfi = __builtin_amdgcn_readlane(fi, win);
+                        const uint32_t wk = __builtin_amdgcn_readlane(k, win);
+                        if (lane == o) {
+                            best.t = wt;
+                            best.bx = wbx;
+                            best.by = wby;
+                            best.fi = wfi;
+                            best.k = wk;
+                            best.w = oW + static_cast<uint32_t>(win);
+                        }
+                    }
+                }
+                if (lane == o) {
+                    pendW += n;
+                    pendC -= n;
+                }
+                coop = __ballot((stage == ST_WALK_C || stage == ST_WALK_S) &&
+                                pendC >= static_cast<uint32_t>(coopMin));
+            }
+            lap(tcCoop);
+        }
+        lap(tcLoop);
+        if (__ballot(stage != ST_IDLE) == 0ull && poolEmpty)
+            break;
+
+        // ================= shade: every lane takes its path to its next ray =============================
+        consume_walk();
+        // light samples until the lane has a shadow ray out or is through its lights (:353-380)
+        while (true) {
+            const int nLights = __popcll(__ballot(stage == ST_LIGHTS && ps.li < p.light_num));
+            if (nLights == 0)
+                break;
+            if (COUNT) {
+                ++cntShades;
+                cntShadeLanes += nLights;
+            }
+            if (stage == ST_LIGHTS && ps.li < p.light_num) {
+                Rng rng{seed, ps.pixel, sample, ps.draw};
+                const kk_light lht = p.lights[ps.li];
+                const float u0 = rng.next();
+                const float u1 = rng.next();
+                ps.draw = rng.draw;
+                LightSample ls = SampleLight(lht, u0, u1, ray.pos);
+                ls.pos = ls.pos + Eps * ls.norm;
+                const f3 in = ls.pos - ray.pos;
+                const float sqrIn = dot(in, in);
+                ray.dir = normalize(in);
+                const float factor = gmax(dot(ray.dir, ps.norm), 0.f) * gmax(dot(-ray.dir, ls.norm), 0.f) /
+                                     sqrIn * lht.area / p.light_tot_area;
+                if (factor < FloatEps)
+                    ++ps.li;
+                else {
+                    ps.fOverPdf = factor / ls.pdf;
+                    start_ray(ray.pos, ray.dir, false, sqrtf(sqrIn) - Eps);
+                }
+            }
+        }
+        lap(tcLights);
+        // after the last light: the path's next direction (:392-425)
+        if (__ballot(stage == ST_LIGHTS) != 0ull) {
+            if (COUNT) {
+                ++cntShades;
+                cntShadeLanes += __popcll(__ballot(stage == ST_LIGHTS));
+            }
+            if (stage == ST_LIGHTS) {
+                const kk_material matr = p.materials[ps.grp];
+                Rng rng{seed, ps.pixel, sample, ps.draw};
+                float pdfIndrct;
+                float u = rng.next();
+                const float u0 = rng.next();
+                const float u1 = rng.next();
+                if (u <= matr.kd_over_kd_add_ks) {
+                    const f3 tngnt = GenerateTangent(ps.norm);
+                    ray.dir = CosineThetaPhiToDirection(sqrtf(1.f - u0), TwoPi * u1, ps.norm, tngnt);
+                    pdfIndrct = dot(ray.dir, ps.norm) * OneOverPi * matr.kd_over_kd_add_ks;
+                } else {
+                    const f3 reflect = normalize(2.f * dot(ps.norm, ps.dirOut) * ps.norm - ps.dirOut);
+                    const f3 tngnt = GenerateTangent(reflect);
+                    ray.dir = ThetaPhiToDirection(acosf(powf(u0, 1.f / (matr.ns + 1.f))), TwoPi * u1, reflect,
+                                                  tngnt);
+                    pdfIndrct = (matr.ns + 1.f) * OneOverTwoPi *
+                                powf(gmax(dot(reflect, ray.dir), 0.f), matr.ns) *
+                                (1.f - matr.kd_over_kd_add_ks);
+                }
+                ps.Lo = ps.Lo + ps.throughout * ps.Li;
+                ps.throughout = ps.throughout *
+                                (dot(ray.dir, ps.norm) / pdfIndrct / RR * BRDF(matr, ray.dir, ps.dirOut, ps.norm));
+                u = rng.next();
+                ps.draw = rng.draw;
+                const bool roulette = u > RR && ps.depth > 1u;
+                ++ps.depth;
+                if (!roulette && ps.depth < p.max_path_depth &&
+                    gmax(ps.throughout.x, gmax(ps.throughout.y, ps.throughout.z)) >= FloatEps)
+                    start_ray(ray.pos, ray.dir, true, 0.f);
+                else
+                    stage = ST_END;
+            }
+        }
+        lap(tcBounce);
+        // finished paths leave, new pixels come in
+        if (__ballot(stage == ST_END || stage == ST_IDLE) != 0ull) {
+            if (COUNT) {
+                ++cntShades;
+                cntShadeLanes += __popcll(__ballot(stage == ST_END || stage == ST_IDLE));
+            }
+            // tone curve, running mean, RGBA8 (:428-429, 623-637)
+            if (stage == ST_END) {
+                f3 Lo = ps.Lo / (ps.Lo + 1.f);
+                Lo.x = powf(Lo.x, 1.f / 2.2f);
+                Lo.y = powf(Lo.y, 1.f / 2.2f);
+                Lo.z = powf(Lo.z, 1.f / 2.2f);
+                const uint32_t idx = ps.pixel;
+                const f3 prev = {accum[3ull * idx], accum[3ull * idx + 1], accum[3ull * idx + 2]};
+                const f3 color = prev + (Lo - prev) / sampleIdx;
+                accum[3ull * idx] = color.x;
+                accum[3ull * idx + 1] = color.y;
+                accum[3ull * idx + 2] = color.z;
+                uchar4 o;
+                o.x = static_cast<uint8_t>(255.f * color.x);
+                o.y = static_cast<uint8_t>(255.f * color.y);
+                o.z = static_cast<uint8_t>(255.f * color.z);
+                o.w = 255;
+                reinterpret_cast<uchar4 *>(rgba)[idx] = o;
+                stage = ST_IDLE;
+            }
+            // idle lanes take the next pixels of the queue (:592-619)
+            const unsigned long long idleMask = __ballot(stage == ST_IDLE);
+            if (idleMask != 0ull && !poolEmpty) {
+                const uint32_t want = __popcll(idleMask);
+                const int leader = __ffsll(static_cast<long long>(idleMask)) - 1;
+                uint32_t base = 0;
+                if (lane == leader)
+                    base = atomicAdd(pixelQueue, want);
+                base = __shfl(base, leader, 64);
+                if (base + want >= queueLen || base + want < base)
+                    poolEmpty = true; // wave-uniform
+                if (stage == ST_IDLE) {
+                    const uint32_t q = base + __popcll(idleMask & lanesBelow);
+                    if (q < queueLen && q >= base) {
+                        const uint32_t tile = q >> 6, in = q & 63u;
+                        const uint32_t tx = tile % tilesX, ty = tile / tilesX;
+                        const int x = static_cast<int>(tx * 8u + (in & 7u));
+                        const int y = y0 + static_cast<int>(ty * 8u + (in >> 3));
+                        if (x < W && y < y1) {
+                            ps.pixel = static_cast<uint32_t>(y) * W + x;
+                            Rng rng{seed, ps.pixel, sample, 0};
+                            m4 invProj, w2s;
+                            m3 rot;
+                            for (int c = 0; c < 4; ++c) {
+                                invProj.c[c] = {p.inv_proj[4 * c], p.inv_proj[4 * c + 1], p.inv_proj[4 * c + 2],
+                                                p.inv_proj[4 * c + 3]};
+                                w2s.c[c] = {p.w2s[4 * c], p.w2s[4 * c + 1], p.w2s[4 * c + 2], p.w2s[4 * c + 3]};
+                            }
+                            for (int c = 0; c < 3; ++c)
+                                rot.c[c] = {f.eye_rot[3 * c], f.eye_rot[3 * c + 1], f.eye_rot[3 * c + 2]};
+                            f4 tmp;
+                            tmp.x = 1.f - rng.next() + x;
+                            tmp.y = 1.f - rng.next() + y;
+                            tmp.z = static_cast<float>(W);
+                            tmp.w = static_cast<float>(H);
+                            tmp.x = (2.f * tmp.x - tmp.z) / tmp.z;
+                            tmp.y = (2.f * tmp.y - tmp.w) / tmp.w;
+                            tmp.z = 1.f;
+                            tmp.w = 1.f;
+                            tmp = invProj * tmp;
+                            f3 dir = {tmp.x, tmp.y, tmp.z};
+                            dir = rot * normalize(dir);
+                            // the reference transforms a temporary by w2s and discards it (:612-614)
+                            dir = normalize(dir);
+                            const f4 pp = w2s * f4{f.eye_pos[0], f.eye_pos[1], f.eye_pos[2], 1.f};
+                            ps.draw = rng.draw;
+                            ps.depth = 0u;
+                            ps.throughout = F3(1.f);
+                            ps.Lo = F3(0.f);
+                            // renderScene's loop test before the first bounce (:318-320)
+                            if (p.max_path_depth > 0)
+                                start_ray(F3(pp.x, pp.y, pp.z), dir, true, 0.f);
+                            else
+                                stage = ST_END;
+                        }
+                    }
+                }
+            }
+        }
+        lap(tcEnd);
+    }
+    if (COUNT) {
+        if (lane == 0) {
+            atomicAdd(&counters[8], static_cast<unsigned long long>(tcLoop));
+            atomicAdd(&counters[9], static_cast<unsigned long long>(tcV));
+            atomicAdd(&counters[10], static_cast<unsigned long long>(tcT));
+            atomicAdd(&counters[14], static_cast<unsigned long long>(tcCoop));
+            atomicAdd(&counters[11], static_cast<unsigned long long>(tcLights));
+            atomicAdd(&counters[12], static_cast<unsigned long long>(tcBounce));
+            atomicAdd(&counters[13], static_cast<unsigned long long>(tcEnd));
+        }
+        // [0] passes of the walk loop (per wave), [1] lanes walking in them, [2] shade phases,
+        // [3] lanes waiting at their start, [4] rays, [5] records visited, [6] triangles tested
+        for (int o = 32; o > 0; o >>= 1) {
+            cntRays += __shfl_xor(cntRays, o, 64);
+            cntVisits += __shfl_xor(cntVisits, o, 64);
+            cntTris += __shfl_xor(cntTris, o, 64);
+        }
+        if (lane == 0) {
+            atomicAdd(&counters[0], cntPasses);
+            atomicAdd(&counters[1], cntWalkLanes);
+            atomicAdd(&counters[2], cntShades);
+            atomicAdd(&counters[3], cntShadeLanes);
+            atomicAdd(&counters[4], cntRays);
+            atomicAdd(&counters[5], cntVisits);
+            atomicAdd(&counters[6], cntTris);
+        }
+    }
+}
+
 __global__ void rng_uniforms_kernel(uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t count,
                                     float *out) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -349,6 +874,27 @@ __global__ void rng_uniforms_kernel(uint32_t seed, uint32_t pixel, uint32_t samp
         for (uint32_t i = 0; i < count; ++i)
             out[i] = rng.next();
     }
+}
+
+static std::atomic<unsigned long long *> g_debugCounters{nullptr};
+
+// Device address of this GPU's copy of the queue heads (every GPU has its own), asked for once.
+static int persist_queue_ptr(uint32_t **out) {
+    constexpr int MAX_DEVICES = 64;
+    static std::mutex mutex;
+    static uint32_t *ptrs[MAX_DEVICES] = {};
+    int dev = -1;
+    KK_HIP_TRY(hipGetDevice(&dev));
+    KK_REQUIRE(dev >= 0 && dev < MAX_DEVICES, "device index out of range");
+    std::lock_guard<std::mutex> lock(mutex);
+    if (!ptrs[dev]) {
+        void *q = nullptr;
+        KK_HIP_TRY(hipGetSymbolAddress(&q, HIP_SYMBOL(persist::g_pixelQueue)));
+        KK_REQUIRE(q != nullptr, "no device address for the pixel queue heads");
+        ptrs[dev] = static_cast<uint32_t *>(q);
+    }
+    *out = ptrs[dev];
+    return KK_OK;
 }
 
 } // namespace pt
@@ -376,13 +922,42 @@ extern "C" int kk_pt_render_sample(const kk_lbvh_device_data *d_lbvh, const kk_p
                    "trace accel sizes out of range");
         const accel::View view =
             accel::make_view(h_scene->trace_accel, h_scene->accel_face_num, h_scene->accel_compacted_face_num);
-        path_trace_kernel<true><<<grid, THREADS, 0, static_cast<hipStream_t>(stream_)>>>(
-            d_lbvh, view, *h_scene, *h_frame, d_accum, d_rgba, width, height, y0, y1, sample_index, seed);
+        // resident workgroups that pull pixels from a queue; the queue head is one of a ring of words
+        // in the library's device image, cleared on this stream before the launch
+        hipStream_t stream = static_cast<hipStream_t>(stream_);
+        uint32_t *queues = nullptr;
+        const int rc = persist_queue_ptr(&queues);
+        if (rc != KK_OK)
+            return rc;
+        static std::atomic<uint32_t> nextSlot{0};
+        uint32_t *head = queues + 32u * (nextSlot.fetch_add(1u) % persist::COUNTER_SLOTS);
+        KK_HIP_TRY(hipMemsetAsync(head, 0, sizeof(uint32_t), stream));
+        const uint32_t queueLen = div_up(width, 8) * div_up(y1 - y0, 8) * 64u;
+        uint32_t pgrid = div_up(queueLen, THREADS);
+        const uint32_t resident = KK_PT_WAVES * static_cast<uint32_t>(device_cu_count());
+        if (pgrid > resident)
+            pgrid = resident;
+        const int walkFirst = persist::WALK_FIRST;
+        const int coopMin = persist::COOP_MIN;
+        unsigned long long *dbg = g_debugCounters.load();
+        if (dbg)
+            path_trace_persistent_kernel<true><<<pgrid, THREADS, 0, stream>>>(
+                view, *h_scene, *h_frame, d_accum, d_rgba, width, height, y0, y1, sample_index, seed, head, dbg,
+                walkFirst, coopMin);
+        else
+            path_trace_persistent_kernel<false><<<pgrid, THREADS, 0, stream>>>(
+                view, *h_scene, *h_frame, d_accum, d_rgba, width, height, y0, y1, sample_index, seed, head,
+                nullptr, walkFirst, coopMin);
     } else
         path_trace_kernel<false><<<grid, THREADS, 0, static_cast<hipStream_t>(stream_)>>>(
             d_lbvh, accel::View{}, *h_scene, *h_frame, d_accum, d_rgba, width, height, y0, y1, sample_index,
             seed);
     KK_LAUNCH_CHECK();
+    return KK_OK;
+}
+
+extern "C" int kk_pt_set_work_counters(unsigned long long *d_counters) {
+    kk::pt::g_debugCounters.store(d_counters);
     return KK_OK;
 }
 

@@ -1,29 +1,32 @@
-"""Path tracer on veach-mis: the 8-wide tree against the binary tree (time, identical accumulation)."""
-import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
-from raytracer_amd.data.scene_setup import make_tracer
-from raytracer_amd.ray_tracer import FrameBuffer
+"""Times the path-tracing leg alone (veach-mis 1920x1080, 16 spp) and prints its parity figures."""
+import json
+import os
+import sys
 
-d = dict(np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests/golden/veach_mis.npz")))
-W, H, spp = 1920, 1080, 16
-res = {}
-for wide in (False, True):
-    tracer, arr, c, proj = make_tracer(d, W, H, "cuda:0")
-    tracer.use_trace_tree = wide
-    fb = FrameBuffer(W, H, "cuda:0")
-    def frame():
-        tracer.curr_accu_spp = 1.0
-        for _ in range(spp):
-            tracer.Render(fb)
-    frame(); torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(3):
-        frame()
-    e1.record(); torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / 3
-    res[wide] = tracer.d_accum.clone()
-    print(f"wide={wide}: {ms:.2f} ms per {spp}-spp frame, {W * H * spp / ms / 1e3:.1f} Mpaths/s", flush=True)
-diff = (res[True] - res[False]).abs()
-print("max abs diff", float(diff.max()), "pixels differing", int((diff.max(dim=2).values > 0).sum()))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from raytracer_amd import bench_pt  # noqa: E402
+
+if __name__ == "__main__":
+    import ctypes
+    import torch
+    from raytracer_amd import _lib
+    with_cpu = "--cpu" in sys.argv
+    print(json.dumps(bench_pt.run("cuda:0", with_cpu=with_cpu)))
+    if "--count" in sys.argv:
+        c = torch.zeros(16, dtype=torch.int64, device="cuda:0")
+        _lib.lib().kk_pt_set_work_counters(ctypes.c_void_p(c.data_ptr()))
+        bench_pt.run("cuda:0", with_cpu=False, frames=1)
+        torch.cuda.synchronize()
+        _lib.lib().kk_pt_set_work_counters(None)
+        v = [int(x) for x in c.cpu()]
+        spp = 32  # warm-up frame + one timed frame of 16 passes
+        print(json.dumps({"walk_passes_per_wave_sum": v[0], "lanes_per_walk_pass": round(v[1] / max(v[0], 1), 1),
+                          "shade_phases": v[2], "lanes_per_shade": round(v[3] / max(v[2], 1), 1),
+                          "rays_per_path": round(v[4] / (1920 * 1080 * spp), 2),
+                          "visits_per_ray": round(v[5] / max(v[4], 1), 2),
+                          "tris_per_ray": round(v[6] / max(v[4], 1), 2),
+                          "walk_passes_per_shade": round(v[0] / max(v[2], 1), 1),
+                          "cycles_frac": {k: round(v[8 + i] / max(sum(v[8:15]), 1), 3) for i, k in
+                                          enumerate(("walk_loop", "visit", "tri", "lights", "bounce", "end", "coop"))},
+                          "cycles_per_walk_pass": round(v[9] / max(v[0], 1), 1),
+                          "cycles_per_shade_section": round(sum(v[11:14]) / max(v[2], 1), 1)}))
