@@ -176,7 +176,7 @@ def main():
 
     dvr = dvr_head = None
     if not args.no_dvr:
-        from raytracer_amd import bench_dvr
+        from benchlib import bench_dvr
         dvr = bench_dvr.run(dev, world, rank, dist, with_cpu=not args.no_cpu)
         dvr_head = bench_dvr.run(dev, world, rank, dist, with_cpu=not args.no_cpu, workload="head",
                                  dim=(128, 256, 256), size=(1920, 1080), cpu_rows=16)
@@ -201,12 +201,18 @@ def main():
                 "empty_visits_per_ray": round(counters["empty_visits"] / R, 2),
                 "lanes_visiting_per_wave_pass": round(counters["visit_lanes"] / passes, 1),
                 "lanes_per_triangle_phase": round(counters["tri_lanes"] / max(counters["tri_phases"], 1), 1)}
-    pmc = os.path.join(ROOT, "profiles", "r01_closest_hit_pmc.json")
-    if os.path.exists(pmc):
-        try:
-            roofline["traffic"] = json.load(open(pmc)).get("hbm_bytes_per_launch")
-        except (OSError, ValueError):
-            pass
+    # HBM traffic needs hardware counters (a rocprofv3 --pmc pass), which a plain run cannot read: the
+    # figure of the committed counter digest of the same kernel and workload is quoted beside a null
+    for name in ("r02_closest_hit_pmc.json", "r01_closest_hit_pmc.json"):
+        pmc = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(pmc):
+            try:
+                roofline["traffic_from_profile"] = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                roofline["traffic_source"] = (f"profiles/{name}: rocprofv3 --pmc passes of scripts/prof_small.py "
+                                              "(same kernel, same workload), not measured in this run")
+            except (OSError, ValueError):
+                pass
+            break
 
     out = {
         "metric": "Mrays/s closest-hit", "value": round(value, 2), "unit": "Mrays/s",
@@ -264,10 +270,14 @@ def main():
 
     # ---- path tracer on the reference's scene (1920x1080, 16 spp), one GPU ---------------------------
     if world == 1 and not args.no_pt:
-        from raytracer_amd import bench_pt
+        from benchlib import bench_pt
         pt = bench_pt.run(dev, with_cpu=not args.no_cpu)
         if pt:
             out["path_trace"] = pt
+        if not args.no_cpu:
+            c1 = bench_pt.config1_cpu()
+            if c1:
+                out["config1_cpu_only"] = c1
 
     # ---- volume path (reported beside the headline value) -------------------------------------------
     if dvr:

@@ -11,11 +11,11 @@ import time
 import numpy as np
 import torch
 
-from . import synthetic as syn
-from .data import camera as cam
-from .data.transfer_function import README_HEAD_TF, README_KINGSNAKE_TF, TransferFunction
-from .dpbx_vdb import DepthBoxVDB, Volume
-from .ray_caster import FrameBuffer, RayCaster, TransferFunctionTable
+from raytracer_amd import synthetic as syn
+from raytracer_amd.data import camera as cam
+from raytracer_amd.data.transfer_function import README_HEAD_TF, README_KINGSNAKE_TF, TransferFunction
+from raytracer_amd.dpbx_vdb import DepthBoxVDB, Volume
+from raytracer_amd.ray_caster import FrameBuffer, RayCaster, TransferFunctionTable
 
 HBM_PEAK_GBPS = 8000.0
 
@@ -56,7 +56,7 @@ def run(dev: str, world: int, rank: int, dist=None, frames: int = 720, warmup: i
         build["classify_GBps"] = round(vol_bytes / (vdb.timings["classify_ms"] * 1e-3) / 1e9, 1)
     bcast_ms = None
     if world > 1:
-        from .multi_gpu import broadcast_vdb
+        from raytracer_amd.multi_gpu import broadcast_vdb
         torch.cuda.synchronize()
         dist.barrier()
         t0 = time.perf_counter()
@@ -84,7 +84,7 @@ def run(dev: str, world: int, rank: int, dist=None, frames: int = 720, warmup: i
     def frame(i):
         caster.SetCameraToWorld(*poses[i])
         if world > 1:
-            from .multi_gpu import gather_stripes
+            from raytracer_amd.multi_gpu import gather_stripes
             caster.RenderDepthBoxVDB(fb, stripes=(rank, world))
             gather_stripes(fb.rgba, world, rank, 0, scratch)
         else:

@@ -10,9 +10,9 @@ import time
 import numpy as np
 import torch
 
-from .data import camera as cam
-from .data.scene_setup import make_tracer
-from .ray_tracer import FrameBuffer
+from raytracer_amd.data import camera as cam
+from raytracer_amd.data.scene_setup import make_tracer
+from raytracer_amd.ray_tracer import FrameBuffer
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -69,3 +69,33 @@ def run(dev: str, size=(1920, 1080), spp: int = 16, frames: int = 5, with_cpu: b
                                 "frac_pixels_beyond": float((err > 1e-3).mean()),
                                 "mean_abs_err": float(np.abs(got[sel] - acc[sel]).mean())}
     return out
+
+
+def config1_cpu(size=(512, 512), spp: int = 1) -> dict:
+    """The first benchmark configuration as stated: the example scene, LBVH build + 512 x 512 path
+    trace at 1 sample per pixel, the reference's logic (the CPU checker) on the host cores, no GPU."""
+    path = os.path.join(ROOT, "tests", "golden", "veach_mis.npz")
+    if not os.path.exists(path):
+        return {}
+    from oracle import kkoracle as ko
+    from raytracer_amd.data.scene_setup import veach_arrays as scene_arrays, veach_camera as scene_camera
+    d = dict(np.load(path))
+    W, H = size
+    cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or (os.cpu_count() or 1)
+    t0 = time.perf_counter()
+    ref = ko.lbvh_build(d["positions"], d["face_position_indices"])
+    build_ms = (time.perf_counter() - t0) * 1e3
+    arr = scene_arrays(d)
+    c, proj = scene_camera(d, W, H)
+    acc = np.zeros((H, W, 3), np.float32)
+    img = np.zeros((H, W, 4), np.uint8)
+    t0 = time.perf_counter()
+    for s in range(1, spp + 1):
+        ko.pt_render_sample(ref, arr, np.eye(4, dtype=np.float32), cam.inverse_projective(proj), c.pos,
+                            c.rotation(), acc, img, float(s))
+    render_ms = (time.perf_counter() - t0) * 1e3
+    return {"workload": f"veach-mis LBVH build + {W}x{H} {spp}-spp path trace, CPU only",
+            "lbvh_build_ms": round(build_ms, 3), "render_ms": round(render_ms, 2), "cores": cores,
+            "kind": "port", "triangles": int(d["face_position_indices"].shape[0]), "leaves": int(ref["M"]),
+            "Mpaths_per_s": round(W * H * spp / (render_ms * 1e-3) / 1e6, 3),
+            "lit_pixel_fraction": round(float((img[..., :3].max(axis=2) > 0).mean()), 4)}

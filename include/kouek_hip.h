@@ -201,6 +201,10 @@ int kk_trace_accel_build_with_leaf_boxes(const kk_lbvh_device_data *d_lbvh, cons
                                          const uint32_t *d_face_pos_idx, uint32_t face_num,
                                          uint32_t compacted_face_num, const float *d_leaf_aabbs,
                                          void *d_accel, size_t accel_bytes, void *stream);
+/* Waits for `stream` and reads the build's status back: KK_ERR_DEVICE when the tree has a path of more
+ * than 32 wide levels (the walks' stacks are made for that many; a tree kk_lbvh_build made never has,
+ * its depth being bounded by the 30 Morton bits) or the buffer holds no tree of these sizes. */
+int kk_trace_accel_check(const void *d_accel, uint32_t face_num, uint32_t compacted_face_num, void *stream);
 size_t kk_closest_hit_accel_workspace_bytes(uint32_t ray_num);
 /* d_counters (optional, uint64[16], zeroed by the caller): [0] 128-byte node records visited,
  * [1] triangles tested, [2] rays traced; diagnostics of the kernel's lane use: [3] passes of the wave

@@ -286,6 +286,18 @@ class OracleVDB:
         A = int(self.param["voxPerAtlasBrick"])
         self.atlas = self.atlas.reshape(self.leaf_num, A, A, A)
 
+    def self_test_rays(self, max_leaves: int = 256):
+        """The reference's test_rayCastVDB (include/ray_caster/test_options.h:88-242) on this VDB: per
+        ray (6 axis-parallel, 4 diagonal, through the centre of the VDB's cube) the leaves met, the
+        count of wrong atlas reverse mappings, the leaves' node indices, and the rays (pos, dir)."""
+        counts = np.zeros(10, np.int32)
+        wrong = np.zeros(10, np.int32)
+        idx = np.full((10, max_leaves), 0xFFFFFFFF, np.uint32)
+        rays = np.zeros((10, 6), np.float32)
+        lib().ko_vdb_self_test_rays(C.c_void_p(self.handle), C.c_int(self.is16), _vp(counts), _vp(wrong),
+                                    _vp(idx), C.c_int(max_leaves), _vp(rays))
+        return counts, wrong, idx, rays
+
     def __del__(self):
         if getattr(self, "handle", None):
             lib().ko_vdb_free(C.c_void_p(self.handle), C.c_int(self.is16))

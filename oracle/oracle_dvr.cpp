@@ -812,9 +812,110 @@ void renderRAW(const T *vol, int dx, int dy, int dz, const float *tf, const Rend
         *samplesOut = total;
 }
 
+// The reference's own host-side self-check of a built VDB, test_rayCastVDB
+// (include/ray_caster/test_options.h:88-242): six axis-parallel and four diagonal rays through the centre
+// of the VDB's cube walk the pools with VDBStack / HDDA3D on the host; at every leaf met the brick's
+// place in the atlas must map back (atlasBrickToNodeIndices) to a node at the same position.
+// Returns per ray: leaves met, wrong reverse mappings, and the leaves' node indices (at most maxLeaves).
+template <typename T>
+static void selfTestRays(const VDB<T> &vdb, int32_t *leafCounts, int32_t *wrong, uint32_t *leafIdx,
+                         int maxLeaves, float *raysOut) {
+    const VDBParameter &p = vdb.param;
+    Ray rays[10];
+    for (int i = 0; i < 6; ++i) { // :112-121
+        const int t0 = i / 2, t1 = i % 2;
+        Ray &r = rays[i];
+        r.dir.x = t0 != 0 ? 0.f : t1 == 0 ? 1.f : -1.f;
+        r.dir.y = t0 != 1 ? 0.f : t1 == 0 ? 1.f : -1.f;
+        r.dir.z = t0 != 2 ? 0.f : t1 == 0 ? 1.f : -1.f;
+        r.pos = vec3{.5f * p.voxPerVDB, .5f * p.voxPerVDB, .5f * p.voxPerVDB} - r.dir * p.voxPerVDB;
+    }
+    for (int i = 0; i < 4; ++i) { // :122-132
+        const int t0 = i & 1, t1 = i & 2;
+        Ray &r = rays[6 + i];
+        r.dir = normalize(vec3{t0 == 0 ? 1.f : -1.f, t1 == 0 ? 1.f : -1.f, 0.f});
+        r.pos = vec3{.5f * p.voxPerVDB, .5f * p.voxPerVDB, .5f * p.voxPerVDB} - r.dir * p.voxPerVDB;
+    }
+    for (int ri = 0; ri < 10; ++ri) {
+        const Ray &eyeRay = rays[ri];
+        for (int k = 0; k < 3; ++k) {
+            raysOut[6 * ri + k] = eyeRay.pos[k];
+            raysOut[6 * ri + 3 + k] = eyeRay.dir[k];
+        }
+        leafCounts[ri] = wrong[ri] = 0;
+        HitShell hit = HitAABB(eyeRay, AABB{{0.f, 0.f, 0.f}, {p.voxPerVDB, p.voxPerVDB, p.voxPerVDB}});
+        if (hit.tEnter >= hit.tExit) { // :143-146 (the reference leaves the whole check here)
+            leafCounts[ri] = -1;
+            continue;
+        }
+        int lev = p.rootLev + 1; // VDBStack, dda.h:13-33
+        float tExits[MaxLevelNum - 1] = {0.f, 0.f};
+        Node nodes[MaxLevelNum - 1] = {};
+        auto push = [&](uint32_t rel, float tExit) {
+            --lev;
+            nodes[lev - 1] = vdb.GetNode(static_cast<uint8_t>(lev), rel);
+            tExits[lev - 1] = tExit;
+        };
+        auto nodePos = [&]() {
+            return vec3{static_cast<float>(nodes[lev - 1].pos[0]), static_cast<float>(nodes[lev - 1].pos[1]),
+                        static_cast<float>(nodes[lev - 1].pos[2])};
+        };
+        push(0, hit.tExit - Eps); // :166-170
+        HDDA3D h = HDDA3D::Create(hit.tEnter + Eps, eyeRay);
+        h.Prepare({0.f, 0.f, 0.f}, p.voxsPerChild[p.rootLev]);
+        h.tCurr += Eps;
+        while (lev != p.rootLev + 1 && [&]() {
+            for (int k = 0; k < 3; ++k)
+                if (h.chPos[k] < 0 || h.chPos[k] >= p.dims[lev])
+                    return false;
+            return true;
+        }()) {
+            h.Next();
+            const Node &curr = nodes[lev - 1];
+            const uint32_t ch = vdb.GetChild(static_cast<uint8_t>(lev), curr.childPoolOffsRelative, h.chPos);
+            if (ch != UndefRltIdx) {
+                if (lev == 1) { // :188-218
+                    const Node leaf = vdb.GetNode(0, ch);
+                    h.tCurr += Eps;
+                    const size_t atlasBrickIdx =
+                        (static_cast<size_t>(leaf.brickPosInAtlas[2]) * p.atlasBrickPerVDB[1] +
+                         leaf.brickPosInAtlas[1]) * p.atlasBrickPerVDB[0] + leaf.brickPosInAtlas[0];
+                    const uint32_t back = vdb.atlasBrickToNodeIndices[atlasBrickIdx];
+                    const Node node = vdb.GetNode(0, back);
+                    if (node.pos[0] != leaf.pos[0] || node.pos[1] != leaf.pos[1] || node.pos[2] != leaf.pos[2])
+                        ++wrong[ri];
+                    if (leafCounts[ri] < maxLeaves)
+                        leafIdx[static_cast<size_t>(ri) * maxLeaves + leafCounts[ri]] = ch;
+                    ++leafCounts[ri];
+                    h.Step();
+                } else { // :219-224
+                    push(ch, h.tNext - Eps);
+                    h.tCurr += Eps;
+                    h.Prepare(nodePos(), p.voxsPerChild[lev]);
+                }
+            } else
+                h.Step();
+            while (h.tCurr >= tExits[lev - 1]) { // :232-239
+                ++lev;
+                if (lev == p.rootLev + 1)
+                    break;
+                h.Prepare(nodePos(), p.voxsPerChild[lev]);
+            }
+        }
+    }
+}
+
 } // namespace
 
 extern "C" {
+
+void ko_vdb_self_test_rays(const void *vdbHandle, int is16, int32_t *leafCounts, int32_t *wrong,
+                           uint32_t *leafIdx, int maxLeaves, float *raysOut) {
+    if (is16)
+        selfTestRays(*static_cast<const VDB<uint16_t> *>(vdbHandle), leafCounts, wrong, leafIdx, maxLeaves, raysOut);
+    else
+        selfTestRays(*static_cast<const VDB<uint8_t> *>(vdbHandle), leafCounts, wrong, leafIdx, maxLeaves, raysOut);
+}
 
 struct ko_dvr_params {
     float w2s[16], invProj[16];

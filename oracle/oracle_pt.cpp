@@ -472,6 +472,22 @@ RGBA8 renderHitTarget(const Scene &s, const AABB &rootAABB, int target, const Ra
 
 extern "C" {
 
+// Material::BRDF (include/ray_tracer/material.h:41-48) for one 64-byte Material.
+void ko_material_brdf(const void *material, const float *dirIn, const float *dirOut, const float *norm,
+                      float *out3) {
+    const vec3 r = BRDF(*static_cast<const Material *>(material), vec3{dirIn[0], dirIn[1], dirIn[2]},
+                        vec3{dirOut[0], dirOut[1], dirOut[2]}, vec3{norm[0], norm[1], norm[2]});
+    out3[0] = r.x, out3[1] = r.y, out3[2] = r.z;
+}
+// Light::SampleQuad / SampleSphere (include/ray_tracer/material.h:95-114) for one 80-byte Light:
+// out7 = pos, norm, pdf.
+void ko_light_sample(const void *light, float u0, float u1, const float *pos, float *out7) {
+    const LightSample r = SampleLight(*static_cast<const Light *>(light), u0, u1, vec3{pos[0], pos[1], pos[2]});
+    out7[0] = r.pos.x, out7[1] = r.pos.y, out7[2] = r.pos.z;
+    out7[3] = r.norm.x, out7[4] = r.norm.y, out7[5] = r.norm.z;
+    out7[6] = r.pdf;
+}
+
 struct ko_pt_scene {
     const void *inodes;
     const uint32_t *faces, *compactedFaces;

@@ -99,6 +99,8 @@ def _declare(l):
     l.kk_trace_accel_layout.argtypes = [u32, u32, vp]
     l.kk_trace_accel_build.argtypes = [vp, vp, vp, u32, u32, vp, sz, vp]
     l.kk_trace_accel_build_with_leaf_boxes.argtypes = [vp, vp, vp, u32, u32, vp, vp, sz, vp]
+    l.kk_trace_accel_check.argtypes = [vp, u32, u32, vp]
+    l.kk_pt_set_work_counters.argtypes = [vp]
     l.kk_closest_hit_accel_workspace_bytes.restype = sz
     l.kk_closest_hit_accel_workspace_bytes.argtypes = [u32]
     l.kk_closest_hit_accel.argtypes = [vp, u32, u32, vp, u32, vp, vp, vp, u32, vp, vp, sz, vp]

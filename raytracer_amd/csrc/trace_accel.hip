@@ -92,6 +92,7 @@ __global__ void init_build_kernel(const kk_lbvh_device_data *__restrict__ lbvh, 
     hdr->nodeNum = nodeNum;
     hdr->nodes = nodes;
     hdr->wideNum = 1;
+    hdr->tooDeep = 0;
     ctl->wideCount = 1;
     ctl->triCount = 0;
     for (int l = 0; l < MAX_LEVELS + 2; ++l)
@@ -424,6 +425,10 @@ __global__ __launch_bounds__(BT) void collapse_tail_kernel(
         __threadfence();
         __syncthreads();
     }
+    // nodes reserved for a level that is never built: a path of more than MAX_LEVELS wide levels
+    if (threadIdx.x == 0 && __atomic_load_n(&ctl->bounds[MAX_LEVELS], __ATOMIC_RELAXED) <
+                                __atomic_load_n(&ctl->bounds[MAX_LEVELS + 1], __ATOMIC_RELAXED))
+        hdr->tooDeep = 1;
 }
 
 // ---- ray ordering ---------------------------------------------------------------------------------
@@ -836,6 +841,30 @@ extern "C" int kk_trace_accel_build(const kk_lbvh_device_data *d_lbvh, const flo
                                     void *stream_) {
     return kk_trace_accel_build_with_leaf_boxes(d_lbvh, d_positions, d_face_pos_idx, face_num,
                                                 compacted_face_num, nullptr, d_accel, accel_bytes, stream_);
+}
+
+extern "C" int kk_trace_accel_check(const void *d_accel, uint32_t face_num, uint32_t compacted_face_num,
+                                    void *stream_) {
+    using namespace kk;
+    using namespace kk::accel;
+    KK_REQUIRE(d_accel != nullptr, "null pointer");
+    KK_REQUIRE(face_num > 0 && compacted_face_num > 0 && compacted_face_num <= face_num,
+               "tree sizes out of range");
+    const Layout l = layout(face_num, compacted_face_num);
+    Header h;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    KK_HIP_TRY(hipMemcpyAsync(&h, static_cast<const char *>(d_accel) + l.header, sizeof(Header),
+                              hipMemcpyDeviceToHost, stream));
+    KK_HIP_TRY(hipStreamSynchronize(stream));
+    if (h.tooDeep) {
+        set_error("the tree is deeper than %d wide levels: the trace-side layout cannot hold it", MAX_LEVELS);
+        return KK_ERR_DEVICE;
+    }
+    if (h.wideNum == 0 || h.faceNum != face_num) {
+        set_error("the accel buffer does not hold a tree of %u faces", face_num);
+        return KK_ERR_DEVICE;
+    }
+    return KK_OK;
 }
 
 extern "C" size_t kk_closest_hit_accel_workspace_bytes(uint32_t ray_num) {

@@ -380,12 +380,10 @@ int fillAtlas(const T *d_volume, uint32_t dx, uint32_t dy, uint32_t dz, const kk
     const size_t A = static_cast<size_t>(p.dims[0]) + 2u * p.apron_dep_wid;
     const size_t lds = 3 * A * A * sizeof(unsigned long long) + A * A * A * sizeof(T);
     if (A <= 64 && p.dims[0] >= 2 && lds <= 150 * 1024) {
-        static bool raised[2] = {false, false}; // the default dynamic LDS limit is 64 KB
-        if (!raised[sizeof(T) - 1]) {
-            KK_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&fill_atlas_lds_kernel<T>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-            raised[sizeof(T) - 1] = true;
-        }
+        // the default dynamic LDS limit is 64 KB; the attribute belongs to the current device's copy
+        // of the kernel, so it is set before every launch (a cheap host-side call)
+        KK_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&fill_atlas_lds_kernel<T>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         fill_atlas_lds_kernel<T><<<plan->leaf_num, FILL_THREADS, lds, static_cast<hipStream_t>(stream)>>>(
             d_volume, dx, dy, dz, d_node_pools + p.node_starts[0], p.dims[0], p.apron_wid,
             p.apron_dep_wid, r, d_atlas);

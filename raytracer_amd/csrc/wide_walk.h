@@ -47,6 +47,8 @@ struct alignas(256) Header {
     uint32_t faceNum, nodeNum;
     const kk_lbvh_node *nodes; // the build's own nodes (parent boxes for the acceptance test)
     uint32_t wideNum;
+    uint32_t tooDeep; // set by the build when wide nodes were left beyond its last level: the tree is
+                      // deeper than the walks' stacks are made for and must not be traced
 };
 
 // A product (b - o) * (1 / d) is within 3 * 2^-24 of the reference's fl((b - o) / d) (one rounding
@@ -386,17 +388,20 @@ struct LaneWalk {
     }
     // next record to visit; false when the walk is over
     __device__ __forceinline__ bool next(const LaneStack &st, const uint2 *deep, uint32_t oct, uint32_t &cur) {
-        if ((grpBits & 0xffu) == 0u) {
+        while ((grpBits & 0xffu) == 0u) {
             if (sp == 0)
                 return false;
             --sp;
             if (sp < LANE_LDS_DEPTH) {
                 grpBase = st.base[sp * st.stride];
                 grpBits = st.bits[sp * st.stride];
-            } else {
+            } else if (sp < LANE_DEPTH) {
                 grpBase = deep[sp - LANE_LDS_DEPTH].x;
                 grpBits = deep[sp - LANE_LDS_DEPTH].y;
             }
+            // else: an entry enter() could not keep. Unreachable for trees the builder accepts (at
+            // most MAX_LEVELS = 32 wide levels, one push per level; deeper trees are flagged by the
+            // build, see Header::tooDeep); popped as an empty group.
         }
         const uint32_t i = static_cast<uint32_t>(__ffs(static_cast<int>(grpBits))) - 1u;
         grpBits &= grpBits - 1u; // the lowest set bit is a pending slot

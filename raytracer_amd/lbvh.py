@@ -71,6 +71,12 @@ class LBVH:
         """Host copy of the 64-byte DeviceData (synchronises)."""
         if self._host_dd is None:
             raw = self.d_device_data.cpu().numpy().tobytes()
+            # the read-back has synchronised: the sort's failure word of the last (re)build is final
+            if self.d_workspace is not None and self.ws_layout is not None:
+                if int(self.stage("error_flag", 1, np.uint32)[0]) != 0:
+                    self._complete = False
+                    raise _lib.KoukeError("radix sort look-back gave up (device error flag set): "
+                                          "the tree of the last build is not valid")
             dd = _lib.LbvhDeviceData.from_buffer_copy(raw)
             self._host_dd = {
                 "rootAABB": np.array(list(dd.root_aabb_min) + list(dd.root_aabb_max), np.float32),
@@ -141,6 +147,11 @@ class LBVH:
                     self.GetDeivceDataDevicePtr(), self.d_positions.data_ptr(), self.d_face_pos_idx.data_ptr(),
                     N, M, leaf_boxes, self.d_accel.data_ptr(), self.d_accel.numel(),
                     _lib.current_stream_ptr()), "kk_trace_accel_build_with_leaf_boxes")
+                if not getattr(self, "_accel_checked", None) == (N, M):
+                    # once per tree shape: the build's own status (depth the walks' stacks can hold)
+                    _lib.check(l.kk_trace_accel_check(self.d_accel.data_ptr(), N, M,
+                                                      _lib.current_stream_ptr()), "kk_trace_accel_check")
+                    self._accel_checked = (N, M)
         return self.d_accel
 
     # -- read-back helpers (parity tests, logs) --------------------------------------------------------

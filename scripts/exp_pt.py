@@ -4,7 +4,7 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from raytracer_amd import bench_pt  # noqa: E402
+from benchlib import bench_pt  # noqa: E402
 
 if __name__ == "__main__":
     import ctypes

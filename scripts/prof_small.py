@@ -20,8 +20,8 @@ if what in ("path1", "all"):
         closest_hit(bvh, rays)
     torch.cuda.synchronize()
 if what in ("dvr", "all"):
-    from raytracer_amd import bench_dvr
+    from benchlib import bench_dvr
     print(bench_dvr.run("cuda:0", 1, 0, None, frames=4, warmup=2, with_cpu=False))
 if what in ("pt",):
-    from raytracer_amd import bench_pt
+    from benchlib import bench_pt
     print(bench_pt.run("cuda:0", spp=4, frames=1, with_cpu=False))

@@ -47,3 +47,16 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libkouek_hip.so")
     with pytest.raises(_lib.KoukeError):
         _lib.lib()
+
+
+def test_product_package_never_imports_the_checker():
+    """oracle/ is test infrastructure: nothing under raytracer_amd/ may import, load or run it."""
+    pkg = os.path.join(ROOT, "raytracer_amd")
+    offenders = []
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".h", ".cpp")) or fn == "Makefile":
+                text = open(os.path.join(dirpath, fn), errors="replace").read()
+                if re.search(r"\boracle\b|kkoracle|libkkref", text):
+                    offenders.append(os.path.relpath(os.path.join(dirpath, fn), ROOT))
+    assert not offenders, offenders

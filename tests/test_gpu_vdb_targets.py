@@ -113,3 +113,51 @@ def test_rows_and_scene_forwarding(oracle):
     assert _lib.lib().kk_dvr_render_target_u8(
         C.byref(caster.vdb.GetDeviceData()), caster.tf.tensor.data_ptr(), C.byref(caster._params),
         C.byref(caster._frame), 7, 0, 0, b.rgba.data_ptr(), W, H, 0, H, _lib.current_stream_ptr()) != 0
+
+
+def test_reference_self_check_rays_through_the_marcher(oracle):
+    """The ten rays of the reference's test_rayCastVDB (include/ray_caster/test_options.h:88-242), traced
+    by the GPU marcher: a 3 x 3 frame whose centre pixel's ray is the test ray (camera at the ray's
+    origin looking along it, world = voxel space). Layer k of the Depths target is lit exactly when the
+    ray meets a (k+1)-th leaf, so the number of lit layers must be the number of leaves the host-side
+    walk of the checker's restated self-check meets, and every layer's pixel must equal the checker's."""
+    shape, l2 = (64, 64, 64), (2, 2, 2)
+    vol = blob_volume(shape, seed=11)
+    rng = np.array([[0, 40]], np.uint8)
+    ref = oracle.OracleVDB(vol, l2, 1, True, rng)
+    counts, wrong, idx, rays = ref.self_test_rays()
+    assert (wrong == 0).all() and float(ref.param["voxPerVDB"]) == 64.0
+    vdb = DepthBoxVDB(DEV)
+    vdb.BuildFrom(Volume(vol, DEV), rng, apron_wid=1, log2_dims=l2, use_depth_box=True)
+    assert vdb.IsComplete()
+    caster = RayCaster(DEV)
+    caster.SetDepthBoxVDB(vdb)
+    caster.SetTransferFunctionTexture(TransferFunctionTable(SNAKE_TF.dat, DEV))
+    w2s = np.diag([1 / 64, 1 / 64, 1 / 64, 1]).astype(np.float32)  # scene = voxel / 64 (exact)
+    caster.SetWorldToScene(w2s)
+    W = H = 3
+    proj = cam.perspective_fov(cam.radians(90.0), W, H, 1.0, 3.0)
+    caster.SetProjection(proj)
+    inv_proj = cam.inverse_projective(proj)
+    fb = FrameBuffer(W, H, DEV)
+    for i in range(10):
+        pos, F = rays[i, :3], rays[i, 3:]
+        helper = np.array([0, 0, 1], np.float32) if abs(F[2]) < 0.5 else np.array([1, 0, 0], np.float32)
+        R = np.cross(F, helper)
+        R /= np.linalg.norm(R)
+        U = np.cross(R, F)
+        rot = np.stack([R, U, -F]).astype(np.float32)  # glm::mat3(R, U, -F): one column per row here
+        caster.SetCameraToWorld(pos, rot)
+        lit = 0
+        for layer in range(int(counts[i]) + 2):
+            caster.SetDepthBoxVDBDisplayLeafLayer(layer)
+            caster.RenderDepthBoxVDB(fb, target="Depths")
+            torch.cuda.synchronize()
+            got = fb.ReadBack()
+            want = oracle.dvr_render_target(ref, w2s, inv_proj, pos, rot, W, H, "Depths",
+                                            display_leaf_layer=layer)
+            np.testing.assert_array_equal(got[1, 1], want[1, 1], err_msg=f"ray {i} layer {layer}")
+            if got[1, 1, 3] == 255:
+                assert lit == layer, "lit layers are consecutive"
+                lit += 1
+        assert lit == counts[i], f"ray {i}: the marcher meets {lit} leaves, the self-check {counts[i]}"

@@ -108,3 +108,54 @@ def test_inspection_targets_on_cpu(oracle, veach):
     rows = oracle.rt_render_target(*args, "Normals", rows=(10, 20))
     full = oracle.rt_render_target(*args, "Normals")
     assert (rows[10:20] == full[10:20]).all() and not rows[:10].any()
+
+
+def test_cpp_host_material_and_light_members_match_checker(oracle, tmp_path):
+    """Material::BRDF, Light::SampleQuad and Light::SampleSphere of the C++ host headers
+    (include/kouek/ray_tracer/material.h; reference include/ray_tracer/material.h:41-48, 95-114) give the
+    checker's bits (both are IEEE arithmetic in glm's order over the same libm)."""
+    import ctypes as C
+    import os
+    import subprocess
+    from raytracer_amd import ray_tracer as rt
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tests", "cpp", "bin", "material_check")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(root, "tests", "cpp"), "-s"])
+    rng = np.random.default_rng(7)
+    n = 400
+    recs, want = [], []
+    lib = oracle.lib()
+    for i in range(n):
+        kd, ks = rng.uniform(0, 1, 3).astype(np.float32), rng.uniform(0, 1, 3).astype(np.float32)
+        m = rt.create_material(kd, ks, np.ones(3, np.float32), 1.5, np.float32(rng.uniform(1, 200)),
+                               np.zeros(3, np.float32))
+        if i % 2:
+            l = rt.create_sphere_light(np.float32(rng.uniform(0.05, 2)), rng.normal(0, 3, 3).astype(np.float32),
+                                       rng.uniform(1, 50, 3).astype(np.float32))
+        else:
+            l = rt.create_quad_light(rng.normal(0, 3, 3).astype(np.float32), rng.normal(0, 1, 3).astype(np.float32),
+                                     rng.normal(0, 1, 3).astype(np.float32), rng.uniform(1, 50, 3).astype(np.float32))
+        v = rng.normal(0, 1, (3, 3))
+        v /= np.linalg.norm(v, axis=1, keepdims=True)
+        f = np.concatenate([v.reshape(-1), rng.uniform(0, 1, 2), rng.normal(0, 4, 3)]).astype(np.float32)
+        if i % 5 == 0:
+            f[6:9] = np.array([0, 1, 0], np.float32)  # |norm.y| >= .999: the other tangent branch
+        mb, lb = np.asarray(m).tobytes(), np.asarray(l).tobytes()
+        assert len(mb) == 64 and len(lb) == 80
+        recs.append(mb + lb + f.tobytes())
+        out = np.zeros(10, np.float32)
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)
+        mbuf, lbuf = np.frombuffer(mb, np.uint8).copy(), np.frombuffer(lb, np.uint8).copy()
+        lib.ko_material_brdf(vp(mbuf), vp(f[0:3].copy()), vp(f[3:6].copy()), vp(f[6:9].copy()), vp(out[:3]))
+        o7 = np.zeros(7, np.float32)
+        lib.ko_light_sample(vp(lbuf), C.c_float(float(f[9])), C.c_float(float(f[10])), vp(f[11:14].copy()), vp(o7))
+        out[3:] = o7
+        want.append(out)
+    src, dst = tmp_path / "in.bin", tmp_path / "out.bin"
+    src.write_bytes(np.uint32(n).tobytes() + b"".join(recs))
+    subprocess.check_call([exe, str(src), str(dst)])
+    got = np.frombuffer(dst.read_bytes(), np.float32).reshape(n, 10)
+    want = np.stack(want)
+    assert np.isfinite(want).all()
+    assert got.tobytes() == want.tobytes()

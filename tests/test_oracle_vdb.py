@@ -235,3 +235,53 @@ def test_oracle_inspection_targets_are_consistent(oracle):
     top = oracle.dvr_render_target(ref, *view, W, H, "PositionsAfterDepthSkip", rows=(30, H))
     np.testing.assert_array_equal(top[30:], p0[30:])
     assert (p0[..., 3] == 255).sum() <= (d0[..., 3] == 255).sum() and (p0[..., 3] == 255).sum() > 0
+
+
+def _leaves_on_axis_line(v, axis, c):
+    """Valid leaves whose brick holds the line through (c, c, c) along `axis`, ordered along it."""
+    B = int(v.param["dims"][0])
+    pos = v.nodes["pos"][:v.leaf_num]
+    sel = np.ones(v.leaf_num, bool)
+    for k in range(3):
+        if k != axis:
+            sel &= (pos[:, k] <= c) & (c < pos[:, k] + B)
+    idx = np.nonzero(sel)[0]
+    return idx[np.argsort(pos[idx, axis])]
+
+
+@pytest.mark.parametrize("shape,l2", [((64, 64, 64), (3, 2, 1)), ((64, 64, 64), (2, 2, 2)),
+                                      ((100, 120, 90), (4, 2, 1))])
+def test_reference_ray_cast_self_check(oracle, shape, l2):
+    """test_rayCastVDB of the reference (include/ray_caster/test_options.h:88-242) restated: ten rays
+    through the centre of the VDB's cube walk the pools with VDBStack / HDDA3D; at each leaf met the
+    atlas map must lead back to the same node (the reference prints "Wrong reverse mapping!!!"
+    otherwise). Beyond that check, an axis-parallel ray must meet exactly the valid leaves on its line,
+    in order."""
+    vol = blob_volume(shape, seed=11)
+    v = oracle.OracleVDB(vol, l2, 1, True, np.array([[0, 40]], np.uint8))
+    counts, wrong, idx, rays = v.self_test_rays()
+    vox = float(v.param["voxPerVDB"])
+    assert vox == float(1 << sum(l2[:int(v.param["rootLev"]) + 1]))
+    assert (counts >= 0).all(), "every ray crosses the VDB's cube"
+    assert (wrong == 0).all()
+    c = 0.5 * vox
+    for i in range(6):
+        axis, back = i // 2, i % 2 == 1
+        want = _leaves_on_axis_line(v, axis, c)
+        if back:
+            want = want[::-1]
+        np.testing.assert_array_equal(idx[i, :counts[i]], want, err_msg=f"ray {i}")
+        assert rays[i, 3 + axis] == (-1.0 if back else 1.0)
+    assert counts[:6].sum() > 0
+    B = int(v.param["dims"][0])
+    for i in range(6, 10):
+        met = idx[i, :counts[i]]
+        assert (met < v.leaf_num).all() and len(set(met.tolist())) == len(met)
+        # the leaves met lie on the diagonal of the z = c plane (up to the brick's own size)
+        o, d = rays[i, :3].astype(np.float64), rays[i, 3:].astype(np.float64)
+        for k in met:
+            centre = v.nodes["pos"][k].astype(np.float64) + 0.5 * B
+            rel = centre - o
+            dist = np.linalg.norm(rel - rel.dot(d) * d)
+            assert dist <= 0.5 * B * np.sqrt(3.0) + 1e-3
+        assert abs(float(np.linalg.norm(d)) - 1.0) < 1e-6 and d[2] == 0.0
