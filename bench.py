@@ -96,12 +96,16 @@ def main():
                 times.append(ev[0].elapsed_time(ev[1]))
         build_ms = float(np.median(times))
     bcast_ms = None
+    comm = None
     if world > 1:
-        from raytracer_amd.multi_gpu import broadcast_lbvh
+        from raytracer_amd.multi_gpu import Communicator, broadcast_lbvh
+        if os.environ.get("KK_BENCH_COMM") == "capi" and os.environ.get("KK_BENCH_REHEARSAL") != "1":
+            # the library's own RCCL communicator (what a C++ host uses) instead of torch.distributed's
+            comm = Communicator(rank, world, dev)
         torch.cuda.synchronize()
         dist.barrier()
         t0 = time.perf_counter()
-        broadcast_lbvh(bvh, src=0)
+        broadcast_lbvh(bvh, src=0, comm=comm)
         torch.cuda.synchronize()
         dist.barrier()
         bcast_ms = (time.perf_counter() - t0) * 1e3
@@ -177,9 +181,9 @@ def main():
     dvr = dvr_head = None
     if not args.no_dvr:
         from benchlib import bench_dvr
-        dvr = bench_dvr.run(dev, world, rank, dist, with_cpu=not args.no_cpu)
+        dvr = bench_dvr.run(dev, world, rank, dist, with_cpu=not args.no_cpu, comm=comm)
         dvr_head = bench_dvr.run(dev, world, rank, dist, with_cpu=not args.no_cpu, workload="head",
-                                 dim=(128, 256, 256), size=(1920, 1080), cpu_rows=16)
+                                 dim=(128, 256, 256), size=(1920, 1080), cpu_rows=16, comm=comm)
 
     if rank != 0:
         if dist:
@@ -233,6 +237,7 @@ def main():
                              "frac_of_hbm_peak": round(gbps / HBM_PEAK_GBPS, 4)}
     if bcast_ms is not None:
         out["lbvh_broadcast_ms"] = round(bcast_ms, 3)
+        out["lbvh_broadcast_bytes"] = int(bvh.d_blob.numel())
 
     # ---- CPU baseline: the reference's logic (oracle port) on the host cores, bounded sample --------
     if world == 1 and not args.no_cpu:

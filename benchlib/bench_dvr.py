@@ -22,7 +22,7 @@ HBM_PEAK_GBPS = 8000.0
 
 def run(dev: str, world: int, rank: int, dist=None, frames: int = 720, warmup: int = 8,
         dim=(1024, 1024, 795), size=(3840, 2160), cpu_rows: int = 24, with_cpu: bool = True,
-        workload: str = "kingsnake") -> dict:
+        workload: str = "kingsnake", comm=None) -> dict:
     """workload "kingsnake": the 4K case above. "head": Head-shape 128x256x256 uint8 volume, README Head
     transfer function, spacing (2, 1, 1), 1920x1080 (pass dim and size accordingly)."""
     head = workload == "head"
@@ -60,7 +60,7 @@ def run(dev: str, world: int, rank: int, dist=None, frames: int = 720, warmup: i
         torch.cuda.synchronize()
         dist.barrier()
         t0 = time.perf_counter()
-        broadcast_vdb(vdb, src=0)
+        broadcast_vdb(vdb, src=0, comm=comm)
         torch.cuda.synchronize()
         dist.barrier()
         bcast_ms = (time.perf_counter() - t0) * 1e3
@@ -79,19 +79,28 @@ def run(dev: str, world: int, rank: int, dist=None, frames: int = 720, warmup: i
         c.Revolve(cam._c("sqrtf", cam._dot(c.pos, c.pos)), 0.5, 0.0)
         poses.append((c.pos.copy(), c.rotation().copy()))
     fb = FrameBuffer(W, H, dev)
-    scratch = {}
+    gatherer = None
+    if world > 1:
+        from raytracer_amd.multi_gpu import StripeGatherer
+        gatherer = StripeGatherer(W, H, world, rank, dev, dst=0, comm=comm)
 
-    def frame(i):
+    def frame(i, gather=True):
         caster.SetCameraToWorld(*poses[i])
-        if world > 1:
-            from raytracer_amd.multi_gpu import gather_stripes
-            caster.RenderDepthBoxVDB(fb, stripes=(rank, world))
-            gather_stripes(fb.rgba, world, rank, 0, scratch)
+        if world > 1 and gather:
+            # this rank's stripes go straight into the block that is sent; the gather of frame i runs
+            # beside the rendering of frame i + 1, rank 0 puts frame i together when its slot comes round
+            buf = gatherer.begin(fb.rgba)
+            caster.RenderDepthBoxVDB(fb, stripes=(rank, world), compact_out=buf)
+            gatherer.submit()
+        elif world > 1:
+            caster.RenderDepthBoxVDB(fb, stripes=(rank, world), compact_out=gatherer.send[0])
         else:
             caster.RenderDepthBoxVDB(fb)
 
     for i in range(warmup):
         frame(i)
+    if gatherer:
+        gatherer.flush(fb.rgba)
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -100,15 +109,40 @@ def run(dev: str, world: int, rank: int, dist=None, frames: int = 720, warmup: i
     ev0.record()
     for i in range(warmup, warmup + frames):
         frame(i)
+    if gatherer:
+        gatherer.flush(fb.rgba)  # the last frames' gathers and their assembly on rank 0 are inside the time
     ev1.record()
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
     wall = time.perf_counter() - t0
+    render_only_ms = same_frame = None
     if dist:
         tt = torch.tensor([wall], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         wall = float(tt.item())
+        # the same frames without the gather: what the per-frame gather costs on top of the rendering
+        n_short = min(frames, 60)
+        torch.cuda.synchronize()
+        dist.barrier()
+        t1 = time.perf_counter()
+        for i in range(warmup, warmup + n_short):
+            frame(i, gather=False)
+        torch.cuda.synchronize()
+        dist.barrier()
+        tt = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        render_only_ms = float(tt.item()) * 1e3 / n_short
+        # one frame through the whole pipeline against the same frame rendered by rank 0 alone
+        frame(warmup)
+        gatherer.flush(fb.rgba)
+        torch.cuda.synchronize()
+        dist.barrier()
+        if rank == 0:
+            got = fb.rgba.clone()
+            caster.RenderDepthBoxVDB(fb)
+            torch.cuda.synchronize()
+            same_frame = bool(torch.equal(got, fb.rgba))
     if rank != 0:
         return {}
     out = {"workload": f"{'Head' if head else 'Kingsnake'}-shape {dim[0]}x{dim[1]}x{dim[2]} uint8, {W}x{H}, "
@@ -117,6 +151,11 @@ def run(dev: str, world: int, rank: int, dist=None, frames: int = 720, warmup: i
            "n_gpus": world, "vdb_build": build}
     if bcast_ms is not None:
         out["vdb_broadcast_ms"] = round(bcast_ms, 3)
+        out["vdb_broadcast_bytes"] = int(vdb.d_blob.numel())
+        out["render_only_ms_per_frame"] = round(render_only_ms, 4)
+        out["gather_us_per_frame"] = round((wall * 1e3 / frames - render_only_ms) * 1e3, 1)
+        out["gathered_frame_equals_single_gpu"] = same_frame
+        out["transport"] = "kk_comm (library RCCL)" if comm is not None else f"torch.distributed/{dist.get_backend()}"
     if world == 1:
         # work counters of one frame: samples taken and bricks entered
         counters = torch.zeros(2, dtype=torch.int64, device=dev)

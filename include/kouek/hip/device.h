@@ -3,6 +3,7 @@
 #ifndef KOUEK_HIP_DEVICE_H
 #define KOUEK_HIP_DEVICE_H
 
+#include <array>
 #include <cstdint>
 #include <cstring>
 #include <iostream>
@@ -133,6 +134,28 @@ template <typename T> class Volume : Noncopyable {
     bool IsComplete() const { return buf.size() == static_cast<size_t>(dim[0]) * dim[1] * dim[2] && buf.size() != 0; }
     const T *Get() const { return buf.data(); }
     const uint32_t *GetDimension() const { return dim; }
+};
+
+// One process per GPU: the library's RCCL communicator (kk_comm_*). Rank 0 calls MakeId() and hands
+// the 128 bytes to the other ranks by whatever means the host program has; every rank then constructs
+// its Communicator with its own GPU current (kk_set_device). Not part of the reference, which renders
+// on one GPU.
+class Communicator : Noncopyable {
+    kk_comm *comm = nullptr;
+    int rank = 0, nranks = 1;
+
+  public:
+    using Id = std::array<uint8_t, KK_COMM_ID_BYTES>;
+    static bool MakeId(Id &id) { return KOUEK_HIP_CHECK("[Communicator Error]", kk_comm_unique_id(id.data())); }
+    Communicator(int nranks, int rank, const Id &id) : rank(rank), nranks(nranks) {
+        if (!KOUEK_HIP_CHECK("[Communicator Error]", kk_comm_init(nranks, rank, id.data(), &comm)))
+            comm = nullptr;
+    }
+    ~Communicator() { kk_comm_destroy(comm); }
+    bool IsComplete() const { return comm != nullptr; }
+    kk_comm *Get() const { return comm; }
+    int GetRank() const { return rank; }
+    int GetRankNum() const { return nranks; }
 };
 
 // Stands in for the 1-D float4 transfer-function texture (256 entries).

@@ -30,10 +30,12 @@ class DepthBoxVDB : Noncopyable {
 
   private:
     bool isComplete = false;
-    HIP::DeviceBuffer<Node> d_nodePools;
-    HIP::DeviceBuffer<RelativeIndexTy> d_childPools;
-    HIP::DeviceBuffer<RelativeIndexTy> d_atlasBrickToNodeIndices;
-    HIP::DeviceBuffer<uint8_t> d_atlas;
+    // Node pools, child pools, atlas map and atlas live in one allocation (kk_vdb_blob_layout_of), so
+    // that Broadcast() is one collective; the reference's separate vectors and CUDA array
+    // (dpbx_vdb.h:98-110) are pieces of it.
+    HIP::DeviceBuffer<uint8_t> d_blob;
+    kk_vdb_plan plan{};
+    uint32_t voxelBytes = 0;
     DeviceData deviceDat{};
     HIP::DeviceBuffer<DeviceData> d_deviceDat;
     static constexpr std::string_view ErrTag = "[DepthBoxVDB Error]";
@@ -83,43 +85,74 @@ class DepthBoxVDB : Noncopyable {
         std::vector<RelativeIndexTy> children(plan.child_num), amap(plan.atlas_map_num);
         if (kk_vdb_wire(&plan, valid.data(), nodes.data(), children.data(), amap.data()) != KK_OK)
             return fail();
-        if (!d_nodePools.assign(nodes) || !d_childPools.assign(children) ||
-            !d_atlasBrickToNodeIndices.assign(amap) || !d_atlas.resize(plan.atlas_voxels * sizeof(T)))
+        this->plan = plan;
+        voxelBytes = sizeof(T);
+        if (!allocBlob())
             return fail();
-        if (Fn<T>::fill(cfg.volTex.Get(), dim[0], dim[1], dim[2], &plan, d_nodePools.data(), rngs.data(), nRng,
-                        reinterpret_cast<T *>(d_atlas.data()), nullptr) != KK_OK)
+        if (kk_memcpy_h2d(deviceDat.node_pools, nodes.data(), sizeof(Node) * nodes.size(), nullptr) != KK_OK ||
+            kk_memcpy_h2d(deviceDat.child_pools, children.data(), 4 * children.size(), nullptr) != KK_OK ||
+            kk_memcpy_h2d(deviceDat.atlas_brick_to_node_indices, amap.data(), 4 * amap.size(), nullptr) != KK_OK)
             return fail();
-        deviceDat.node_pools = d_nodePools.data();
-        deviceDat.child_pools = d_childPools.data();
-        deviceDat.atlas_brick_to_node_indices = d_atlasBrickToNodeIndices.data();
-        deviceDat.atlas = d_atlas.data();
-        deviceDat.leaf_num = plan.leaf_num;
-        deviceDat.voxel_bytes = sizeof(T);
-        deviceDat.vdb_param = plan.param;
-        if (!d_deviceDat.size())
-            d_deviceDat.resize(1);
-        kk_memcpy_h2d(d_deviceDat.data(), &deviceDat, sizeof(deviceDat), nullptr);
+        if (Fn<T>::fill(cfg.volTex.Get(), dim[0], dim[1], dim[2], &plan, deviceDat.node_pools, rngs.data(), nRng,
+                        static_cast<T *>(deviceDat.atlas), nullptr) != KK_OK)
+            return fail();
         kk_stream_synchronize(nullptr);
-        std::cout << "Build VDB with\n\tNode pools of size " << d_nodePools.size() << "x" << sizeof(Node)
-                  << "\n\tChild pools of size " << d_childPools.size() << "x4\n\tMaps from atlas brick to node index of size "
-                  << d_atlasBrickToNodeIndices.size() << "x4\n\tAtlas of " << plan.leaf_num << " bricks of "
+        std::cout << "Build VDB with\n\tNode pools of size " << plan.node_num << "x" << sizeof(Node)
+                  << "\n\tChild pools of size " << plan.child_num << "x4\n\tMaps from atlas brick to node index of size "
+                  << plan.atlas_map_num << "x4\n\tAtlas of " << plan.leaf_num << " bricks of "
                   << plan.param.vox_per_atlas_brick << "^3x" << sizeof(T) << "\n";
+        isComplete = true;
+    }
+
+    // Several GPUs: the VDB built on rank `root` reaches every rank of `comm` in two collectives (the
+    // 176-byte plan, then the one allocation). Not part of the reference.
+    void Broadcast(const HIP::Communicator &comm, int root = 0) {
+        const bool sender = comm.GetRank() == root;
+        if (sender && !isComplete) {
+            std::cerr << ErrTag << " Broadcast of an incomplete VDB.\n";
+            return;
+        }
+        struct {
+            kk_vdb_plan plan;
+            uint64_t voxelBytes;
+        } head{plan, voxelBytes};
+        if (!KOUEK_HIP_CHECK(ErrTag.data(), kk_comm_broadcast_host(comm.Get(), &head, sizeof(head), root, nullptr)))
+            return;
+        if (!sender) {
+            isComplete = false;
+            clear();
+            plan = head.plan;
+            voxelBytes = static_cast<uint32_t>(head.voxelBytes);
+            if (!allocBlob()) {
+                std::cerr << ErrTag << " " << kk_last_error() << "\n";
+                return;
+            }
+        }
+        if (!KOUEK_HIP_CHECK(ErrTag.data(),
+                             kk_vdb_broadcast(comm.Get(), d_blob.data(), &plan, voxelBytes, root, nullptr)) ||
+            kk_stream_synchronize(nullptr) != KK_OK)
+            return;
         isComplete = true;
     }
 
     bool IsComplete() const { return isComplete; }
     const DeviceData *GetDeivceDataDevicePtr() const { return d_deviceDat.data(); }
     const DeviceData &GetDeviceData() const { return deviceDat; }
-    size_t GetNodePoolsSize() const { return d_nodePools.size(); }
-    size_t GetChildPoolsSize() const { return d_childPools.size(); }
-    size_t GetAtlasBrickToNodeIndicesSize() const { return d_atlasBrickToNodeIndices.size(); }
+    size_t GetNodePoolsSize() const { return isComplete ? plan.node_num : 0; }
+    size_t GetChildPoolsSize() const { return isComplete ? plan.child_num : 0; }
+    size_t GetAtlasBrickToNodeIndicesSize() const { return isComplete ? plan.atlas_map_num : 0; }
 
   private:
-    void clear() {
-        d_nodePools.clear();
-        d_childPools.clear();
-        d_atlasBrickToNodeIndices.clear();
-        d_atlas.clear();
+    void clear() { d_blob.clear(); }
+    // the blob for `plan` / `voxelBytes`, the host DeviceData pointing into it and its device mirror
+    bool allocBlob() {
+        kk_vdb_blob_layout lay;
+        if (kk_vdb_blob_layout_of(&plan, voxelBytes, &lay) != KK_OK || !d_blob.resize(lay.total) ||
+            kk_vdb_blob_device_data(d_blob.data(), &plan, voxelBytes, &deviceDat) != KK_OK)
+            return false;
+        if (!d_deviceDat.size() && !d_deviceDat.resize(1))
+            return false;
+        return kk_memcpy_h2d(d_deviceDat.data(), &deviceDat, sizeof(deviceDat), nullptr) == KK_OK;
     }
 };
 

@@ -104,6 +104,38 @@ class RayCaster : Noncopyable {
                            static_cast<int>(rndrTarget), displayLev, displayLeafLayer, rndrTo.Get(), rndrSz.x,
                            rndrSz.y, 0, rndrSz.y, nullptr));
     }
+
+    // Several GPUs (not part of the reference): every rank of `comm` renders its round-robin 16-row
+    // stripes of the Scene target straight into the block it sends, the blocks are gathered on rank
+    // `root` and put back in image order in `rndrTo` there (other ranks pass any frame buffer of the
+    // size; theirs is left alone). Blocking form of the exchange: one frame, waited for.
+    template <typename T>
+    void RenderDepthBoxVDBGathered(HIP::FrameBuffer &rndrTo, const ivec2 &rndrSz, const HIP::Communicator &comm,
+                                   int root = 0) {
+        if (!vdb || !tfTex || !vdb->IsComplete()) {
+            std::cerr << ErrTag << " at " << __FILE__ << ":" << __LINE__ << ". vdb or tfTex are not set.\n";
+            return;
+        }
+        const int n = comm.GetRankNum(), r = comm.GetRank();
+        const size_t blockBytes = static_cast<size_t>(kk_stripes_per_rank(rndrSz.y, n)) * 16 * rndrSz.x * 4;
+        if (stripeSend.size() != blockBytes && (!stripeSend.resize(blockBytes) || !stripeSend.zero()))
+            return;
+        if (r == root && stripeBlocks.size() != blockBytes * n && !stripeBlocks.resize(blockBytes * n))
+            return;
+        auto fn = sizeof(T) == 1 ? kk_dvr_render_stripes_compact_u8 : kk_dvr_render_stripes_compact_u16;
+        if (!KOUEK_HIP_CHECK(ErrTag.data(), fn(&vdb->GetDeviceData(), tfTex->Get(), &rndrParam, &rndrParamPerFrame,
+                                               stripeSend.data(), rndrSz.x, rndrSz.y, r, n, nullptr, nullptr)) ||
+            !KOUEK_HIP_CHECK(ErrTag.data(), kk_gather_stripes(comm.Get(), stripeSend.data(), stripeBlocks.data(),
+                                                              rndrSz.x, rndrSz.y, root, nullptr)))
+            return;
+        if (r == root)
+            KOUEK_HIP_CHECK(ErrTag.data(),
+                            kk_unstripe_rgba(stripeBlocks.data(), n, rndrSz.x, rndrSz.y, rndrTo.Get(), nullptr));
+        kk_stream_synchronize(nullptr);
+    }
+
+  private:
+    HIP::DeviceBuffer<uint8_t> stripeSend, stripeBlocks;
 };
 
 } // namespace RayCaster

@@ -44,15 +44,18 @@ class LBVH : Noncopyable {
 
   private:
     bool isComplete = false;
-    HIP::DeviceBuffer<IndexTy> d_faces;
-    HIP::DeviceBuffer<IndexTy> d_compactedFaces;
-    HIP::DeviceBuffer<InternalNode> d_internalNodes;
-    HIP::DeviceBuffer<float> d_positions;
-    HIP::DeviceBuffer<IndexTy> d_facePositionIndices;
+    // The tree and the mesh it indexes live in one allocation (kk_lbvh_blob_layout_of: DeviceData,
+    // positions, face indices, faces, compactedFaces, internalNodes), so that Broadcast() is one
+    // collective; the reference's separate thrust vectors (lbvh.h:47-52) are pieces of it.
+    HIP::DeviceBuffer<uint8_t> d_blob;
+    kk_lbvh_blob_layout blob{};
+    uint32_t faceNum = 0, vertNum = 0;
     HIP::DeviceBuffer<uint8_t> d_workspace;
     size_t leafAABBsOffs = 0; // of the per-leaf boxes inside d_workspace
-    HIP::DeviceBuffer<DeviceData> d_deviceDat;
+    bool hasLeafAABBs = false;
     DeviceData deviceDat{};
+
+    template <typename T> T *piece(uint64_t offs) const { return reinterpret_cast<T *>(d_blob.data() + offs); }
 
     static constexpr std::string_view StatTag = "[LBVH Status]";
     static constexpr std::string_view ErrTag = "[LBVH Error]";
@@ -72,23 +75,24 @@ class LBVH : Noncopyable {
         if (!KOUEK_HIP_CHECK(ErrTag.data(), kk_lbvh_workspace_layout(N, V, 0, &lay)))
             return;
         static_assert(sizeof(vec3) == 12 && sizeof(uvec3) == 12, "tightly packed vectors expected");
-        bool ok = d_positions.resize(3ull * V) && d_facePositionIndices.resize(3ull * N) &&
-                  d_faces.resize(N) && d_compactedFaces.resize(N) && d_internalNodes.resize(N) &&
-                  d_workspace.resize(lay.total_bytes) && (d_deviceDat.size() || d_deviceDat.resize(1));
-        ok = ok && kk_memcpy_h2d(d_positions.data(), inputMesh.positions.data(), 12ull * V, nullptr) == KK_OK;
-        ok = ok && kk_memcpy_h2d(d_facePositionIndices.data(), inputMesh.facePositionIndices.data(), 12ull * N, nullptr) == KK_OK;
+        if (!KOUEK_HIP_CHECK(ErrTag.data(), kk_lbvh_blob_layout_of(N, V, &blob)))
+            return;
+        faceNum = N, vertNum = V;
+        bool ok = d_blob.resize(blob.total) && d_workspace.resize(lay.total_bytes);
+        ok = ok && kk_memcpy_h2d(piece<float>(blob.positions), inputMesh.positions.data(), 12ull * V, nullptr) == KK_OK;
+        ok = ok && kk_memcpy_h2d(piece<IndexTy>(blob.face_pos_idx), inputMesh.facePositionIndices.data(), 12ull * N, nullptr) == KK_OK;
         if (!ok) {
             std::cerr << ErrTag << " " << kk_last_error() << "\n";
             return;
         }
         if (!KOUEK_HIP_CHECK(ErrTag.data(),
-                             kk_lbvh_build(d_positions.data(), V, d_facePositionIndices.data(), N,
-                                           d_faces.data(), d_compactedFaces.data(),
-                                           reinterpret_cast<kk_lbvh_node *>(d_internalNodes.data()),
-                                           reinterpret_cast<kk_lbvh_device_data *>(d_deviceDat.data()),
-                                           d_workspace.data(), lay.total_bytes, 0, nullptr)))
+                             kk_lbvh_build(piece<float>(blob.positions), V, piece<IndexTy>(blob.face_pos_idx), N,
+                                           piece<IndexTy>(blob.faces), piece<IndexTy>(blob.compacted),
+                                           piece<kk_lbvh_node>(blob.nodes),
+                                           piece<kk_lbvh_device_data>(blob.device_data), d_workspace.data(),
+                                           lay.total_bytes, 0, nullptr)))
             return;
-        if (kk_memcpy_d2h(&deviceDat, d_deviceDat.data(), sizeof(deviceDat), nullptr) != KK_OK)
+        if (kk_memcpy_d2h(&deviceDat, piece<DeviceData>(blob.device_data), sizeof(deviceDat), nullptr) != KK_OK)
             return;
         uint32_t sortError = 0;
         kk_memcpy_d2h(&sortError, d_workspace.data() + lay.error_flag, 4, nullptr);
@@ -99,31 +103,61 @@ class LBVH : Noncopyable {
         std::cout << StatTag << " Builded LBVH.\n\tcompact num: " << deviceDat.compactedFaceNum
                   << ", face num: " << deviceDat.faceNum << "\n";
         leafAABBsOffs = lay.leaf_aabbs;
+        hasLeafAABBs = true;
         isComplete = true;
         if (!logPath.empty())
             writeLog(inputMesh, logPath);
     }
 
+    // Several GPUs: the tree built on rank `root` (BuildFrom there; the other ranks call nothing before)
+    // reaches every rank of `comm` in two collectives - the sizes, then the tree's one allocation - and
+    // every rank's DeviceData points at its own copy. Not part of the reference.
+    void Broadcast(const HIP::Communicator &comm, int root = 0) {
+        const bool sender = comm.GetRank() == root;
+        if (sender && !isComplete) {
+            std::cerr << ErrTag << " Broadcast of an incomplete LBVH.\n";
+            return;
+        }
+        uint32_t sizes[2] = {faceNum, vertNum};
+        if (!KOUEK_HIP_CHECK(ErrTag.data(), kk_comm_broadcast_host(comm.Get(), sizes, sizeof(sizes), root, nullptr)))
+            return;
+        if (!sender) {
+            isComplete = false;
+            clear();
+            faceNum = sizes[0], vertNum = sizes[1];
+            if (!KOUEK_HIP_CHECK(ErrTag.data(), kk_lbvh_blob_layout_of(faceNum, vertNum, &blob)) ||
+                !d_blob.resize(blob.total)) {
+                std::cerr << ErrTag << " " << kk_last_error() << "\n";
+                return;
+            }
+        }
+        if (!KOUEK_HIP_CHECK(ErrTag.data(),
+                             kk_lbvh_broadcast(comm.Get(), d_blob.data(), faceNum, vertNum, root, nullptr)))
+            return;
+        if (kk_memcpy_d2h(&deviceDat, piece<DeviceData>(blob.device_data), sizeof(deviceDat), nullptr) != KK_OK)
+            return;
+        isComplete = true;
+    }
+
     bool IsComplete() const { return isComplete; }
-    const DeviceData *GetDeivceDataDevicePtr() const { return d_deviceDat.data(); }
+    const DeviceData *GetDeivceDataDevicePtr() const { return piece<DeviceData>(blob.device_data); }
     const DeviceData &GetDeviceData() const { return deviceDat; }
 
     // Device copies of the mesh arrays the tree indexes; the renderer shares them.
-    const float *GetDevicePositions() const { return d_positions.data(); }
-    const IndexTy *GetDeviceFacePositionIndices() const { return d_facePositionIndices.data(); }
-    // float[compactedFaceNum][6]: the boxes of the leaves, left in the workspace by the build.
+    const float *GetDevicePositions() const { return piece<float>(blob.positions); }
+    const IndexTy *GetDeviceFacePositionIndices() const { return piece<IndexTy>(blob.face_pos_idx); }
+    // float[compactedFaceNum][6]: the boxes of the leaves, left in the workspace by the build (a tree
+    // that was received from another rank has none).
     const float *GetDeviceLeafAABBs() const {
-        return isComplete ? reinterpret_cast<const float *>(d_workspace.data() + leafAABBsOffs) : nullptr;
+        return isComplete && hasLeafAABBs ? reinterpret_cast<const float *>(d_workspace.data() + leafAABBsOffs)
+                                          : nullptr;
     }
 
   private:
     void clear() {
-        d_faces.clear();
-        d_compactedFaces.clear();
-        d_internalNodes.clear();
-        d_positions.clear();
-        d_facePositionIndices.clear();
+        d_blob.clear();
         d_workspace.clear();
+        hasLeafAABBs = false;
     }
 
     // The text log of the reference (src/ray_tracer/lbvh.cu:330-384), same sections and line formats.
@@ -138,8 +172,9 @@ class LBVH : Noncopyable {
             os << "of:" << i << "-> v0:" << in.facePositionIndices[i][0] + 1
                << ", v1:" << in.facePositionIndices[i][1] + 1 << ", v2:" << in.facePositionIndices[i][2] + 1 << "\n";
         os << "\n[LBVH/Compacts]\n";
-        auto compacts = d_compactedFaces.to_host(deviceDat.compactedFaceNum);
-        auto faces = d_faces.to_host();
+        std::vector<IndexTy> compacts(deviceDat.compactedFaceNum), faces(deviceDat.faceNum);
+        kk_memcpy_d2h(compacts.data(), piece<IndexTy>(blob.compacted), 4ull * compacts.size(), nullptr);
+        kk_memcpy_d2h(faces.data(), piece<IndexTy>(blob.faces), 4ull * faces.size(), nullptr);
         for (IndexTy i = 0; i < compacts.size(); ++i) {
             auto fi = compacts[i];
             auto fiEnd = i == compacts.size() - 1 ? faces.size() - 1 : compacts[i + 1];
@@ -151,7 +186,9 @@ class LBVH : Noncopyable {
             os << "\n";
         }
         os << "\n[LBVH/INodes]\n";
-        auto inodes = d_internalNodes.to_host(deviceDat.compactedFaceNum > 1 ? deviceDat.compactedFaceNum - 1 : 0);
+        std::vector<InternalNode> inodes(deviceDat.compactedFaceNum > 1 ? deviceDat.compactedFaceNum - 1 : 0);
+        if (!inodes.empty())
+            kk_memcpy_d2h(inodes.data(), piece<InternalNode>(blob.nodes), sizeof(InternalNode) * inodes.size(), nullptr);
         for (IndexTy i = 0; i < inodes.size(); ++i) {
             bool lLeaf = (inodes[i].lft & InternalNode::ChildIsLeafMask) != 0;
             bool rLeaf = (inodes[i].rht & InternalNode::ChildIsLeafMask) != 0;

@@ -462,6 +462,19 @@ int kk_dvr_render_stripes_u16(const kk_vdb_device_data *h_vdb, const float *d_tf
                               uint8_t *d_rgba, int width, int height, int stripe_first,
                               int stripe_stride, unsigned long long *d_counters, void *stream);
 
+/* The same stripes written one after the other into d_stripes uint8[kk_stripes_per_rank][16][W][4]
+ * (the j-th stripe of this launch, image stripe stripe_first + j * stripe_stride, goes to rows
+ * [16 j, 16 j + 16) of d_stripes): the contiguous block a rank hands to kk_gather_stripes. Rows of a
+ * last, partial stripe beyond the image are not written. */
+int kk_dvr_render_stripes_compact_u8(const kk_vdb_device_data *h_vdb, const float *d_tf,
+                                     const kk_dvr_params *h_params, const kk_dvr_frame *h_frame,
+                                     uint8_t *d_stripes, int width, int height, int stripe_first,
+                                     int stripe_stride, unsigned long long *d_counters, void *stream);
+int kk_dvr_render_stripes_compact_u16(const kk_vdb_device_data *h_vdb, const float *d_tf,
+                                      const kk_dvr_params *h_params, const kk_dvr_frame *h_frame,
+                                      uint8_t *d_stripes, int width, int height, int stripe_first,
+                                      int stripe_stride, unsigned long long *d_counters, void *stream);
+
 /* RenderDepthBoxVDB with any DPBXVDBRenderTarget (include/ray_caster/ray_caster.h:85; kernels
  * src/ray_caster/ray_caster_dpbx_vdb.cu:284-437): AABBs colours the nodes of level display_lev
  * (RayCaster::SetDepthBoxVDBDisplayLevel, 0 = leaves ... root_lev), Depths and
@@ -497,6 +510,68 @@ int kk_raw_render_u16(const uint16_t *d_volume, uint32_t dx, uint32_t dy, uint32
                       const kk_dvr_params *h_params, const kk_dvr_frame *h_frame, int target,
                       uint8_t *d_rgba, int width, int height, int y0, int y1,
                       unsigned long long *d_counters, void *stream);
+
+/* ================================================================================================
+ * Several GPUs (one process per GPU, RCCL over xGMI). No counterpart in the reference, which renders on
+ * one GPU: the structure (LBVH + mesh, or VDB + atlas) is built once on one rank and broadcast, every
+ * rank renders its share of the image (round-robin 16-row stripes) or traces its share of the rays,
+ * and the stripes are gathered to one rank. RCCL is opened at run time by the first kk_comm_* call.
+ * ============================================================================================== */
+typedef struct kk_comm kk_comm;
+#define KK_COMM_ID_BYTES 128
+/* Rank 0 makes the id and hands it to the other ranks by any means the host has (a file, MPI, a
+ * socket); every rank then calls kk_comm_init with its own GPU current (kk_set_device). */
+int kk_comm_unique_id(void *h_id /* KK_COMM_ID_BYTES */);
+int kk_comm_init(int nranks, int rank, const void *h_id, kk_comm **out);
+int kk_comm_destroy(kk_comm *comm);
+int kk_comm_rank(const kk_comm *comm, int *rank, int *nranks);
+/* One collective over `bytes` of device memory, enqueued on `stream`. */
+int kk_comm_broadcast(kk_comm *comm, void *d_buf, size_t bytes, int root, void *stream);
+/* A few host bytes (sizes, a plan; at most 4096) from root to every rank; waits for `stream`. */
+int kk_comm_broadcast_host(kk_comm *comm, void *h_buf, size_t bytes, int root, void *stream);
+/* Every rank's bytes_per_rank bytes land at d_recv + rank * bytes_per_rank on root (d_recv may be NULL
+ * elsewhere): one grouped receive per peer, i.e. one direct link each. Enqueued on `stream`. */
+int kk_comm_gather(kk_comm *comm, const void *d_send, void *d_recv, size_t bytes_per_rank, int root,
+                   void *stream);
+
+/* An LBVH and the mesh it indexes in ONE device allocation, so that it travels in one collective:
+ * the 64-byte kk_lbvh_device_data first, then positions float[V][3], face_pos_idx uint32[N][3], faces
+ * uint32[N], compacted uint32[N], nodes kk_lbvh_node[N], each 256-byte aligned. Point kk_lbvh_build at
+ * these pieces (d_out = blob + device_data). */
+typedef struct kk_lbvh_blob_layout {
+    uint64_t device_data, positions, face_pos_idx, faces, compacted, nodes, total;
+} kk_lbvh_blob_layout;
+int kk_lbvh_blob_layout_of(uint32_t face_num, uint32_t vert_num, kk_lbvh_blob_layout *out);
+/* Rewrites the three pointers of the blob's kk_lbvh_device_data for this blob's own address (device
+ * pointers do not travel); the counts and the root box stay. Enqueued on `stream`. */
+int kk_lbvh_blob_bind(void *d_blob, uint32_t face_num, uint32_t vert_num, void *stream);
+/* kk_comm_broadcast of the whole blob, then kk_lbvh_blob_bind on every rank. face_num and vert_num
+ * must be known on every rank (kk_comm_broadcast_host). */
+int kk_lbvh_broadcast(kk_comm *comm, void *d_blob, uint32_t face_num, uint32_t vert_num, int root,
+                      void *stream);
+
+/* A Depth-Box VDB in one allocation: node pools, child pools, atlas map, atlas (256-byte aligned
+ * pieces, sizes from the plan). */
+typedef struct kk_vdb_blob_layout {
+    uint64_t node_pools, child_pools, atlas_map, atlas, total;
+} kk_vdb_blob_layout;
+int kk_vdb_blob_layout_of(const kk_vdb_plan *plan, uint32_t voxel_bytes, kk_vdb_blob_layout *out);
+/* Host-side: the device-data struct (pointers into this blob, parameters from the plan). */
+int kk_vdb_blob_device_data(void *d_blob, const kk_vdb_plan *plan, uint32_t voxel_bytes,
+                            kk_vdb_device_data *h_out);
+/* One collective over the blob. The plan (176 bytes) must be known on every rank first. */
+int kk_vdb_broadcast(kk_comm *comm, void *d_blob, const kk_vdb_plan *plan, uint32_t voxel_bytes, int root,
+                     void *stream);
+
+/* Image stripes: stripe s = rows [16 s, 16 s + 16); rank r renders stripes r, r + nranks, ... into a
+ * compact block of kk_stripes_per_rank(height, nranks) stripes (kk_dvr_render_stripes_compact_*).
+ * kk_gather_stripes collects the blocks on root (d_blocks uint8[nranks][per][16][W][4], root only);
+ * kk_unstripe_rgba puts them back in image order: d_rgba uint8[H][W][4]. */
+int kk_stripes_per_rank(int height, int nranks);
+int kk_gather_stripes(kk_comm *comm, const uint8_t *d_stripes, uint8_t *d_blocks, int width, int height,
+                      int root, void *stream);
+int kk_unstripe_rgba(const uint8_t *d_blocks, int nranks, int width, int height, uint8_t *d_rgba,
+                     void *stream);
 
 #ifdef __cplusplus
 }

@@ -62,6 +62,15 @@ class DvrFrame(C.Structure):
     _fields_ = [("eye_pos", C.c_float * 3), ("eye_rot", C.c_float * 9)]
 
 
+class LbvhBlobLayout(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("device_data", "positions", "face_pos_idx", "faces", "compacted",
+                                          "nodes", "total")]
+
+
+class VdbBlobLayout(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("node_pools", "child_pools", "atlas_map", "atlas", "total")]
+
+
 assert C.sizeof(VdbParam) == 128 and C.sizeof(VdbDeviceData) == 176 and C.sizeof(VdbPlan) == 176
 
 KK_LBVH_KEEP_STAGES = 1
@@ -114,6 +123,24 @@ def _declare(l):
         getattr(l, f"kk_raw_render_{sfx}").argtypes = [vp, u32, u32, u32, vp, vp, vp, i32, vp, i32, i32, i32, i32, vp, vp]
         getattr(l, f"kk_dvr_render_stripes_{sfx}").argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]
         getattr(l, f"kk_dvr_render_target_{sfx}").argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, i32, i32, i32, i32, vp]
+    for sfx in ("u8", "u16"):
+        getattr(l, f"kk_dvr_render_stripes_compact_{sfx}").argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]
+    l.kk_comm_unique_id.argtypes = [vp]
+    l.kk_comm_init.argtypes = [i32, i32, vp, C.POINTER(vp)]
+    l.kk_comm_destroy.argtypes = [vp]
+    l.kk_comm_rank.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
+    l.kk_comm_broadcast.argtypes = [vp, vp, sz, i32, vp]
+    l.kk_comm_broadcast_host.argtypes = [vp, vp, sz, i32, vp]
+    l.kk_comm_gather.argtypes = [vp, vp, vp, sz, i32, vp]
+    l.kk_lbvh_blob_layout_of.argtypes = [u32, u32, C.POINTER(LbvhBlobLayout)]
+    l.kk_lbvh_blob_bind.argtypes = [vp, u32, u32, vp]
+    l.kk_lbvh_broadcast.argtypes = [vp, vp, u32, u32, i32, vp]
+    l.kk_vdb_blob_layout_of.argtypes = [vp, u32, C.POINTER(VdbBlobLayout)]
+    l.kk_vdb_blob_device_data.argtypes = [vp, vp, u32, vp]
+    l.kk_vdb_broadcast.argtypes = [vp, vp, vp, u32, i32, vp]
+    l.kk_stripes_per_rank.argtypes = [i32, i32]
+    l.kk_gather_stripes.argtypes = [vp, vp, vp, i32, i32, i32, vp]
+    l.kk_unstripe_rgba.argtypes = [vp, i32, i32, i32, vp, vp]
     l.kk_vdb_plan_build.argtypes = [u32, u32, u32, vp, C.c_uint8, i32, vp, vp]
     l.kk_vdb_wire.argtypes = [vp, vp, vp, vp, vp]
     for name in ("kk_malloc", "kk_free", "kk_memcpy_h2d", "kk_memcpy_d2h", "kk_memset",

@@ -266,7 +266,7 @@ __global__ __launch_bounds__(THREADS) void dvr_kernel(const kk_vdb_device_data v
                                                       const kk_dvr_params rp, const kk_dvr_frame fr,
                                                       uint8_t *__restrict__ rgba, int W, int H, int y0,
                                                       int y1, int stripeFirst, int stripeStride,
-                                                      unsigned long long *counters) {
+                                                      int compact, unsigned long long *counters) {
     __shared__ float4 s_tf[TF_LDS];
     __shared__ float s_norm[256];
     const int tid = threadIdx.x;
@@ -605,7 +605,9 @@ __global__ __launch_bounds__(THREADS) void dvr_kernel(const kk_vdb_device_data v
             o.z = static_cast<uint8_t>(255.f * rgb.z);
             o.w = static_cast<uint8_t>(255.f * a);
         }
-        reinterpret_cast<uchar4 *>(rgba)[static_cast<size_t>(y) * W + x] = o;
+        // compact: this launch's stripes one after the other (the block a rank sends to the gatherer)
+        const int outRow = compact ? static_cast<int>(blockIdx.y) * 16 + (wave >> 1) * 8 + (lane >> 3) : y;
+        reinterpret_cast<uchar4 *>(rgba)[static_cast<size_t>(outRow) * W + x] = o;
     }
 
     if (COUNT) {
@@ -1037,7 +1039,8 @@ int launchRaw(const T *d_volume, uint32_t dx, uint32_t dy, uint32_t dz, const fl
 template <typename T>
 int launch(const kk_vdb_device_data *h_vdb, const float *d_tf, const kk_dvr_params *h_params,
            const kk_dvr_frame *h_frame, uint8_t *d_rgba, int width, int height, int y0, int y1,
-           int stripeFirst, int stripeStride, unsigned long long *d_counters, hipStream_t stream) {
+           int stripeFirst, int stripeStride, unsigned long long *d_counters, hipStream_t stream,
+           int compact = 0) {
     KK_REQUIRE(h_vdb && d_tf && h_params && h_frame && d_rgba, "null pointer");
     KK_REQUIRE(h_vdb->node_pools && h_vdb->child_pools && h_vdb->atlas, "VDB arrays missing");
     KK_REQUIRE(h_vdb->voxel_bytes == sizeof(T), "voxel type does not match the VDB");
@@ -1059,7 +1062,7 @@ int launch(const kk_vdb_device_data *h_vdb, const float *d_tf, const kk_dvr_para
 #define KK_LAUNCH_DVR(COUNT, SHADING)                                                              \
     dvr_kernel<T, COUNT, SHADING><<<grid, THREADS, 0, stream>>>(*h_vdb, d_tf, *h_params, *h_frame, d_rgba, \
                                                                 width, height, y0, y1, stripeFirst,       \
-                                                                stripeStride, d_counters)
+                                                                stripeStride, compact, d_counters)
     const bool shading = h_params->use_shading != 0;
     if (d_counters) {
         if (shading)
@@ -1111,6 +1114,24 @@ extern "C" int kk_dvr_render_stripes_u16(const kk_vdb_device_data *h_vdb, const 
     return kk::dvr::launch<uint16_t>(h_vdb, d_tf, h_params, h_frame, d_rgba, width, height, 0, height,
                                      stripe_first, stripe_stride, d_counters,
                                      static_cast<hipStream_t>(stream));
+}
+extern "C" int kk_dvr_render_stripes_compact_u8(const kk_vdb_device_data *h_vdb, const float *d_tf,
+                                                const kk_dvr_params *h_params, const kk_dvr_frame *h_frame,
+                                                uint8_t *d_stripes, int width, int height, int stripe_first,
+                                                int stripe_stride, unsigned long long *d_counters,
+                                                void *stream) {
+    return kk::dvr::launch<uint8_t>(h_vdb, d_tf, h_params, h_frame, d_stripes, width, height, 0, height,
+                                    stripe_first, stripe_stride, d_counters,
+                                    static_cast<hipStream_t>(stream), 1);
+}
+extern "C" int kk_dvr_render_stripes_compact_u16(const kk_vdb_device_data *h_vdb, const float *d_tf,
+                                                 const kk_dvr_params *h_params, const kk_dvr_frame *h_frame,
+                                                 uint8_t *d_stripes, int width, int height, int stripe_first,
+                                                 int stripe_stride, unsigned long long *d_counters,
+                                                 void *stream) {
+    return kk::dvr::launch<uint16_t>(h_vdb, d_tf, h_params, h_frame, d_stripes, width, height, 0, height,
+                                     stripe_first, stripe_stride, d_counters,
+                                     static_cast<hipStream_t>(stream), 1);
 }
 extern "C" int kk_raw_render_u8(const uint8_t *d_volume, uint32_t dx, uint32_t dy, uint32_t dz,
                                 const float *d_tf, const kk_dvr_params *h_params,

@@ -55,6 +55,7 @@ class DepthBoxVDB:
         self.plan = None
         self.d_node_pools = self.d_child_pools = self.d_atlas_brick_to_node = self.d_atlas = None
         self.device_data = None
+        self.d_blob = self.blob_layout = None
         self.voxel_bytes = 0
         self.timings = {}
 
@@ -130,10 +131,10 @@ class DepthBoxVDB:
                                      nodes.ctypes.data_as(C.c_void_p), children.ctypes.data_as(C.c_void_p),
                                      amap.ctypes.data_as(C.c_void_p)), "kk_vdb_wire")
             tw.append(time.perf_counter())
-            self.d_node_pools = torch.from_numpy(nodes.view(np.uint8)).to(dev)
-            self.d_child_pools = torch.from_numpy(children.view(np.int32)).to(dev)
-            self.d_atlas_brick_to_node = torch.from_numpy(amap.view(np.int32)).to(dev)
-            self.d_atlas = torch.empty(int(plan.atlas_voxels) * vol.itemsize, dtype=torch.uint8, device=dev)
+            self.alloc_blob(plan, vol.itemsize)
+            self.d_node_pools.copy_(torch.from_numpy(nodes.view(np.uint8)))
+            self.d_child_pools.copy_(torch.from_numpy(children.view(np.int32)))
+            self.d_atlas_brick_to_node.copy_(torch.from_numpy(amap.view(np.int32)))
             tw.append(time.perf_counter())
             ev[2].record()
             _lib.check(getattr(l, f"kk_vdb_fill_atlas_{sfx}")(
@@ -145,22 +146,26 @@ class DepthBoxVDB:
         self.timings = {"classify_ms": ev[0].elapsed_time(ev[1]), "fill_atlas_ms": ev[2].elapsed_time(ev[3])}
         for k, name in enumerate(("classify_and_readback", "plan", "wire", "upload_alloc", "fill_and_sync")):
             self.timings["host_" + name + "_ms"] = (tw[k + 1] - tw[k]) * 1e3
-        self.plan, self.voxel_bytes = plan, vol.itemsize
         self.host_nodes, self.host_children, self.host_atlas_map = nodes, children, amap
-        dd = _lib.VdbDeviceData()
-        dd.node_pools, dd.child_pools = self.d_node_pools.data_ptr(), self.d_child_pools.data_ptr()
-        dd.atlas_brick_to_node_indices = self.d_atlas_brick_to_node.data_ptr()
-        dd.atlas, dd.leaf_num, dd.voxel_bytes = self.d_atlas.data_ptr(), plan.leaf_num, vol.itemsize
-        dd.vdb_param = plan.param
-        self.device_data = dd
 
-    def rebind(self) -> None:
-        """Rewrites the device pointers of the device-data struct (after the arrays were received from
-        another rank)."""
-        dd = self.device_data
-        dd.node_pools, dd.child_pools = self.d_node_pools.data_ptr(), self.d_child_pools.data_ptr()
-        dd.atlas_brick_to_node_indices = self.d_atlas_brick_to_node.data_ptr()
-        dd.atlas = self.d_atlas.data_ptr()
+    def alloc_blob(self, plan, voxel_bytes: int) -> None:
+        """Node pools, child pools, atlas map and atlas in one allocation (one collective carries them to
+        another GPU, kk_vdb_blob_layout_of); the arrays are views, the device-data struct points into it."""
+        lay = _lib.VdbBlobLayout()
+        _lib.check(_lib.lib().kk_vdb_blob_layout_of(C.byref(plan), int(voxel_bytes), C.byref(lay)),
+                   "kk_vdb_blob_layout_of")
+        b = torch.empty(int(lay.total), dtype=torch.uint8, device=self.device)
+        self.d_blob, self.blob_layout = b, lay
+        self.plan, self.voxel_bytes = plan, int(voxel_bytes)
+        piece = lambda off, nbytes: b[int(off):int(off) + nbytes]
+        self.d_node_pools = piece(lay.node_pools, int(plan.node_num) * 32)
+        self.d_child_pools = piece(lay.child_pools, int(plan.child_num) * 4).view(torch.int32)
+        self.d_atlas_brick_to_node = piece(lay.atlas_map, int(plan.atlas_map_num) * 4).view(torch.int32)
+        self.d_atlas = piece(lay.atlas, int(plan.atlas_voxels) * int(voxel_bytes))
+        dd = _lib.VdbDeviceData()
+        _lib.check(_lib.lib().kk_vdb_blob_device_data(b.data_ptr(), C.byref(plan), int(voxel_bytes), C.byref(dd)),
+                   "kk_vdb_blob_device_data")
+        self.device_data = dd
 
     def atlas_to_host(self) -> np.ndarray:
         A = int(self.plan.param.vox_per_atlas_brick)

@@ -38,7 +38,10 @@ class LBVH:
         self.d_positions = self.d_face_pos_idx = None
         self.d_faces = self.d_compacted = self.d_nodes = None
         self.d_device_data = self.d_workspace = None
+        self.d_blob = self.blob_layout = None
         self.d_accel = None
+        self._accel_stale = True
+        self._accel_checked = None
         self._host_dd = None
         self.ws_layout = None
         self.face_num = 0
@@ -87,25 +90,40 @@ class LBVH:
         return self._host_dd
 
     # -- implementation --------------------------------------------------------------------------
+    def alloc_blob(self, N: int, V: int) -> None:
+        """The tree and the mesh it indexes live in one allocation (so that they travel to other GPUs in
+        one collective, kk_lbvh_blob_layout_of); the arrays are views into it."""
+        lay = _lib.LbvhBlobLayout()
+        _lib.check(_lib.lib().kk_lbvh_blob_layout_of(N, V, C.byref(lay)), "kk_lbvh_blob_layout_of")
+        b = torch.empty(int(lay.total), dtype=torch.uint8, device=self.device)
+        self.d_blob, self.blob_layout, self.face_num = b, lay, N
+        piece = lambda off, nbytes: b[int(off):int(off) + nbytes]
+        self.d_device_data = piece(lay.device_data, 64)
+        self.d_device_data.zero_()
+        self.d_positions = piece(lay.positions, 12 * V).view(torch.float32).reshape(V, 3)
+        self.d_face_pos_idx = piece(lay.face_pos_idx, 12 * N).view(torch.int32).reshape(N, 3)
+        self.d_faces = piece(lay.faces, 4 * N).view(torch.int32)
+        self.d_compacted = piece(lay.compacted, 4 * N).view(torch.int32)
+        self.d_nodes = piece(lay.nodes, 32 * N)
+
     def _build(self, positions, tri, keep_stages, sync):
         l = _lib.lib()
         dev = self.device
-        self.d_positions = _to_device(positions, torch.float32, dev).reshape(-1, 3)
+        pos_t = positions if isinstance(positions, torch.Tensor) else torch.from_numpy(
+            np.ascontiguousarray(positions, dtype=np.float32))
         tri_t = tri if isinstance(tri, torch.Tensor) else torch.from_numpy(
             np.ascontiguousarray(tri).astype(np.uint32, copy=False).view(np.int32))
-        self.d_face_pos_idx = tri_t.to(device=dev).contiguous().view(torch.int32).reshape(-1, 3)
-        V, N = self.d_positions.shape[0], self.d_face_pos_idx.shape[0]
+        pos_t, tri_t = pos_t.reshape(-1, 3), tri_t.reshape(-1, 3)
+        V, N = pos_t.shape[0], tri_t.shape[0]
         if N == 0 or V == 0:
             raise _lib.KoukeError("empty mesh: the build needs at least one face")
-        self.face_num = N
+        self.alloc_blob(N, V)
+        self.d_positions.copy_(pos_t.to(torch.float32))
+        self.d_face_pos_idx.copy_(tri_t.view(torch.int32) if tri_t.dtype != torch.int32 else tri_t)
         flags = _lib.KK_LBVH_KEEP_STAGES if keep_stages else 0
         lay = _lib.LbvhWsLayout()
         _lib.check(l.kk_lbvh_workspace_layout(N, V, flags, C.byref(lay)), "kk_lbvh_workspace_layout")
         self.ws_layout = lay
-        self.d_faces = torch.empty(N, dtype=torch.int32, device=dev)
-        self.d_compacted = torch.empty(N, dtype=torch.int32, device=dev)
-        self.d_nodes = torch.empty(N * 32, dtype=torch.uint8, device=dev)
-        self.d_device_data = torch.zeros(64, dtype=torch.uint8, device=dev)
         self.d_workspace = torch.empty(lay.total_bytes, dtype=torch.uint8, device=dev)
         self.rebuild(flags)
         if sync:

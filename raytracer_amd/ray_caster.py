@@ -106,10 +106,12 @@ class RayCaster:
     DPBXVDB_RENDER_TARGETS = ("Scene", "AABBs", "Depths", "PositionsAfterDepthSkip")
 
     def RenderDepthBoxVDB(self, fb: FrameBuffer, rows=None, counters=None, stripes=None,
-                          target: str = "Scene") -> None:
+                          target: str = "Scene", compact_out=None) -> None:
         """One frame into fb. `rows` = (y0, y1) renders those rows only; `stripes` = (first, stride)
-        renders the 16-row stripes first, first + stride, ... (one GPU's share; Scene only). `target` is
-        a DPBXVDBRenderTarget (include/ray_caster/ray_caster.h:85)."""
+        renders the 16-row stripes first, first + stride, ... (one GPU's share; Scene only); with
+        `compact_out` (uint8 tensor [per, 16, W, 4]) those stripes are written one after the other into
+        it instead of into fb (the block a rank sends to the gathering rank). `target` is a
+        DPBXVDBRenderTarget (include/ray_caster/ray_caster.h:85)."""
         if self.vdb is None or self.tf is None or not self.vdb.IsComplete():
             print(f"{self.ErrTag} vdb or tfTex are not set.", file=sys.stderr)
             return
@@ -123,14 +125,21 @@ class RayCaster:
                     self._display_leaf_layer, fb.rgba.data_ptr(), fb.width, fb.height, int(y0), int(y1),
                     _lib.current_stream_ptr()), "kk_dvr_render_target")
             return
-        if stripes is not None:
+        out_ptr = fb.rgba.data_ptr()
+        if stripes is not None and compact_out is not None:
+            fn, a, b = getattr(_lib.lib(), f"kk_dvr_render_stripes_compact_{sfx}"), stripes[0], stripes[1]
+            need = _lib.lib().kk_stripes_per_rank(fb.height, stripes[1]) * 16 * fb.width * 4
+            if compact_out.numel() * compact_out.element_size() < need:
+                raise _lib.KoukeError("compact_out is smaller than this rank's stripes")
+            out_ptr = compact_out.data_ptr()
+        elif stripes is not None:
             fn, a, b = getattr(_lib.lib(), f"kk_dvr_render_stripes_{sfx}"), stripes[0], stripes[1]
         else:
             fn = getattr(_lib.lib(), f"kk_dvr_render_{sfx}")
             a, b = rows if rows is not None else (0, fb.height)
         with torch.cuda.device(self.device):
             _lib.check(fn(C.byref(self.vdb.GetDeviceData()), self.tf.tensor.data_ptr(),
-                          C.byref(self._params), C.byref(self._frame), fb.rgba.data_ptr(), fb.width,
+                          C.byref(self._params), C.byref(self._frame), out_ptr, fb.width,
                           fb.height, int(a), int(b),
                           counters.data_ptr() if counters is not None else None,
                           _lib.current_stream_ptr()), "kk_dvr_render")

@@ -114,6 +114,28 @@ int main(int argc, char **argv) {
     kk_stream_synchronize(nullptr);
     dfb.ReadBack(img);
     save(out + "/dvr_rgba.u8", img);
+    // the several-GPU calls with a one-rank communicator: both structures broadcast (each a single
+    // allocation), the frame rendered as compact stripes, gathered and put back in image order
+    {
+        HIP::Communicator::Id id;
+        if (HIP::Communicator::MakeId(id)) {
+            HIP::Communicator comm(1, 0, id);
+            if (!comm.IsComplete())
+                return 1;
+            lbvh->Broadcast(comm, 0);
+            vdb->Broadcast(comm, 0);
+            if (!lbvh->IsComplete() || !vdb->IsComplete())
+                return 1;
+            HIP::FrameBuffer gfb(dsz);
+            caster.RenderDepthBoxVDBGathered<uint8_t>(gfb, dsz, comm, 0);
+            gfb.ReadBack(img);
+            save(out + "/dvr_gathered_rgba.u8", img);
+            // the tree is still the tree after its broadcast: one more sample on top
+            tracer.Render(fb, sz);
+            save(out + "/pt_accum_after_broadcast.f32", tracer.ReadAccumulation());
+        } else
+            std::fprintf(stderr, "no RCCL on this machine: %s\n", kk_last_error());
+    }
     // the same view without empty-space skipping
     auto rawVol = std::make_shared<HIP::Volume<uint8_t>>(vol, vdim[0], vdim[1], vdim[2]);
     caster.SetRAWVolume(rawVol);

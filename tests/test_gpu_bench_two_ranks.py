@@ -27,3 +27,7 @@ def test_two_rank_rehearsal():
     assert out["n_gpus"] == 2 and out["value"] > 0 and out["scaling"] == "weak"
     assert out["dvr"]["n_gpus"] == 2 and out["dvr"]["fps"] > 0
     assert "lbvh_broadcast_ms" in out and "vdb_broadcast_ms" in out["dvr"]
+    # the frame put together from two ranks' stripes is the frame one GPU renders, byte for byte
+    assert out["dvr"]["gathered_frame_equals_single_gpu"] is True
+    assert out["dvr_head_1080p"]["gathered_frame_equals_single_gpu"] is True
+    assert "gather_us_per_frame" in out["dvr"] and out["dvr"]["render_only_ms_per_frame"] > 0

@@ -94,6 +94,17 @@ def test_cpp_host_classes_match_checker(oracle, veach, tmp_path):
     dgot = np.fromfile(outd / "dvr_rgba.u8", np.uint8).reshape(DH, DW, 4)
     np.testing.assert_array_equal(dgot[..., 3], want[..., 3])
     assert np.abs(dgot[..., :3].astype(int) - want[..., :3].astype(int)).max() <= 1
+    # the one-rank communicator round trip: the gathered frame is the frame; the tracer still works on
+    # the tree after its broadcast (a third sample equals the checker's third)
+    if os.path.exists(outd / "dvr_gathered_rgba.u8"):
+        ggot = np.fromfile(outd / "dvr_gathered_rgba.u8", np.uint8)
+        assert ggot.tobytes() == dgot.tobytes()
+        oracle.pt_render_sample(ref, arr, np.eye(4, dtype=np.float32), cam.inverse_projective(proj),
+                                c.pos, c.rotation(), acc, img, float(spp + 1))
+        got3 = np.fromfile(outd / "pt_accum_after_broadcast.f32", np.float32).reshape(H, W, 3)
+        assert float((np.abs(got3 - acc).max(axis=2) > 1e-3).mean()) <= 2e-3
+    else:
+        assert "no RCCL on this machine" in r.stderr
     # RAW-volume caster and two inspection targets through the C++ classes
     rwant, _ = oracle.raw_render(vol, HEAD_TF.dat, w2s, cam.inverse_projective(dproj), dc.pos,
                                  dc.rotation(), DW, DH)

@@ -72,3 +72,72 @@ def test_broadcast_vdb_and_gather_stripes(group):
     torch.cuda.synchronize()
     assert whole.ReadBack().tobytes() == striped.ReadBack().tobytes()
     assert (whole.ReadBack()[..., 3] > 0).mean() > 0.05
+
+
+def test_library_communicator_one_rank():
+    """The kk_comm_* entry points (the library's own RCCL communicator, what a C++ host uses) with one
+    rank: tree and VDB broadcast as one allocation each, stripes rendered compact, gathered on a side
+    stream two frames deep and put back in image order - the frames must be the plainly rendered ones."""
+    from raytracer_amd import _lib, multi_gpu, synthetic as syn
+    from raytracer_amd.dpbx_vdb import DepthBoxVDB, Volume
+    from raytracer_amd.lbvh import LBVH
+    from raytracer_amd.ray_caster import FrameBuffer, RayCaster, TransferFunctionTable
+    from raytracer_amd.ray_tracer import closest_hit
+    from vol_util import HEAD_TF, dvr_setup
+    try:
+        comm = multi_gpu.Communicator(0, 1, DEV)
+    except _lib.KoukeError as e:
+        pytest.skip(f"RCCL communicator could not be created: {e}")
+    pos, tri = syn.triangle_soup(50_000)
+    rays = syn.incoherent_rays(20_000)
+    bvh = LBVH(DEV)
+    bvh.BuildFrom(pos, tri)
+    before = [x.cpu().numpy() for x in closest_hit(bvh, rays)]
+    dd_before = dict(bvh.GetDeviceData())
+    multi_gpu.broadcast_lbvh(bvh, src=0, comm=comm)
+    torch.cuda.synchronize()
+    dd_after = bvh.GetDeviceData()
+    assert dd_after["faces"] == dd_before["faces"] == bvh.d_faces.data_ptr()
+    assert dd_after["compactedFaceNum"] == dd_before["compactedFaceNum"]
+    after = [x.cpu().numpy() for x in closest_hit(bvh, rays)]
+    for a, b in zip(before, after):
+        assert a.tobytes() == b.tobytes()
+    assert comm.broadcast_host(b"sizes: 12345", 0) == b"sizes: 12345"
+
+    dim = (64, 128, 128)
+    vdb = DepthBoxVDB(DEV)
+    vdb.BuildFrom(Volume(syn.head_volume(dim), DEV), HEAD_TF.empty_scalar_ranges, apron_wid=1,
+                  log2_dims=(4, 3, 3), use_depth_box=True)
+    multi_gpu.broadcast_vdb(vdb, src=0, comm=comm)
+    W, H = 164, 120  # the last stripe is partial
+    caster = RayCaster(DEV)
+    caster.SetDepthBoxVDB(vdb)
+    caster.SetTransferFunctionTexture(TransferFunctionTable(HEAD_TF.dat, DEV))
+    g = multi_gpu.StripeGatherer(W, H, 1, 0, DEV, comm=comm)
+    whole, gathered = FrameBuffer(W, H, DEV), FrameBuffer(W, H, DEV)
+    want, got = [], []
+    for orbit in (0, 9, 40, 77):
+        w2s, c, proj = dvr_setup(dim, (2, 1, 1), W, H, 1.0, orbit)
+        caster.SetWorldToScene(w2s)
+        caster.SetProjection(proj)
+        caster.SetCameraToWorld(c.pos, c.rotation())
+        caster.RenderDepthBoxVDB(whole)
+        torch.cuda.synchronize()
+        want.append(whole.ReadBack().copy())
+        buf = g.begin(gathered.rgba)
+        if g.frames >= 2:
+            torch.cuda.synchronize()
+            got.append(gathered.ReadBack().copy())
+        caster.RenderDepthBoxVDB(gathered, stripes=(0, 1), compact_out=buf)
+        g.submit()
+    g._wait(g.slot, gathered.rgba)
+    torch.cuda.synchronize()
+    got.append(gathered.ReadBack().copy())
+    g._wait(g.slot ^ 1, gathered.rgba)
+    torch.cuda.synchronize()
+    got.append(gathered.ReadBack().copy())
+    assert len(got) == 4
+    for a, b in zip(got, want):
+        assert a.tobytes() == b.tobytes()
+    assert (want[0][..., 3] > 0).mean() > 0.05
+    comm.close()

@@ -1,4 +1,8 @@
-"""The N > 1 path rehearsed with two gloo ranks on the CPU: structure broadcast and stripe gather."""
+"""The N > 1 path rehearsed with two gloo ranks on the CPU. The structures are the CPU checker's (a real
+LBVH of a triangle soup, a real Depth-Box VDB) and the stripes are rendered by the checker's marcher, so
+what crosses the rank boundary is what the GPU ranks exchange: the tree's one allocation, the VDB's one
+allocation, compact stripe blocks gathered two frames deep."""
+import ctypes as C
 import os
 import sys
 
@@ -11,66 +15,137 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _fill_tree(bvh, ko, syn, n_tri, seed):
+    """An LBVH object on host tensors holding the checker's tree of a soup of n_tri triangles."""
+    from raytracer_amd import _lib, multi_gpu
+    pos, tri = syn.triangle_soup(n_tri, seed=seed)
+    ref = ko.lbvh_build(pos, tri)
+    N, V, M = n_tri, pos.shape[0], int(ref["M"])
+    bvh._clear()
+    bvh.alloc_blob(N, V)
+    bvh.d_positions.copy_(torch.from_numpy(pos))
+    bvh.d_face_pos_idx.copy_(torch.from_numpy(tri.view(np.int32)))
+    bvh.d_faces.copy_(torch.from_numpy(ref["faces"].view(np.int32)))
+    bvh.d_compacted[:M].copy_(torch.from_numpy(ref["compactedFaces"].view(np.int32)))
+    bvh.d_nodes[:(M - 1) * 32].copy_(torch.from_numpy(ref["internalNodes"].view(np.uint8).reshape(-1)))
+    dd = _lib.LbvhDeviceData()
+    box = ref["rootAABB"].reshape(-1)
+    for k in range(3):
+        dd.root_aabb_min[k], dd.root_aabb_max[k] = float(box[k]), float(box[3 + k])
+    dd.face_num, dd.compacted_face_num = N, M
+    bvh.d_device_data.copy_(torch.from_numpy(np.frombuffer(bytes(dd), np.uint8).copy()))
+    multi_gpu.bind_lbvh_blob(bvh)
+    bvh._complete = True
+    return ref
+
+
+def _check_tree(bvh, ref, n_tri):
+    dd = bvh.GetDeviceData()
+    M = int(ref["M"])
+    assert bvh.IsComplete() and dd["faceNum"] == n_tri and dd["compactedFaceNum"] == M
+    assert dd["faces"] == bvh.d_faces.data_ptr() and dd["internalNodes"] == bvh.d_nodes.data_ptr()
+    assert dd["compactedFaces"] == bvh.d_compacted.data_ptr()
+    np.testing.assert_array_equal(dd["rootAABB"], ref["rootAABB"].reshape(-1))
+    assert bvh.d_faces.numpy().view(np.uint32).tobytes() == ref["faces"].tobytes()
+    assert bvh.d_compacted[:M].numpy().view(np.uint32).tobytes() == ref["compactedFaces"].tobytes()
+    assert bvh.d_nodes[:(M - 1) * 32].numpy().tobytes() == ref["internalNodes"].tobytes()
+
+
 def _worker(rank, world, port, out_dir):
     sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ["OMP_NUM_THREADS"] = "2"
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from raytracer_amd import _lib, multi_gpu
-    from raytracer_amd.lbvh import LBVH
+    from oracle import kkoracle as ko
+    from raytracer_amd import _lib, multi_gpu, synthetic as syn
+    from raytracer_amd.data import camera as cam
     from raytracer_amd.dpbx_vdb import DepthBoxVDB
+    from raytracer_amd.lbvh import LBVH
+    from vol_util import HEAD_TF, dvr_setup
 
-    # ---- LBVH broadcast: arrays made on rank 0 arrive bit for bit, the header is rebuilt locally ----
+    # ---- LBVH broadcast, twice into the same object: the second tree must replace the first whole -------
     bvh = LBVH("cpu")
-    N, V, M = 1000, 3000, 990
-    if rank == 0:
-        g = torch.Generator().manual_seed(1)
-        bvh.face_num = N
-        bvh.d_positions = torch.rand((V, 3), generator=g)
-        bvh.d_face_pos_idx = torch.arange(3 * N, dtype=torch.int32).reshape(N, 3)
-        bvh.d_faces = torch.randperm(N, generator=g).to(torch.int32)
-        bvh.d_compacted = torch.arange(N, dtype=torch.int32)
-        bvh.d_nodes = torch.randint(0, 255, (N * 32,), generator=g, dtype=torch.uint8)
-        multi_gpu.write_lbvh_device_data(bvh, np.array([0, 0, 0, 1, 1, 1], np.float32), N, M)
-        bvh._complete = True
-    multi_gpu.broadcast_lbvh(bvh, src=0)
-    dd = bvh.GetDeviceData()
-    assert bvh.IsComplete() and dd["faceNum"] == N and dd["compactedFaceNum"] == M
-    assert dd["faces"] == bvh.d_faces.data_ptr() and dd["internalNodes"] == bvh.d_nodes.data_ptr()
-    torch.save({"faces": bvh.d_faces, "nodes": bvh.d_nodes[:(M - 1) * 32], "pos": bvh.d_positions},
-               os.path.join(out_dir, f"bvh{rank}.pt"))
+    for n_tri, seed in ((3000, 11), (1700, 12)):
+        if rank == 0:
+            _fill_tree(bvh, ko, syn, n_tri, seed)
+        else:  # leftovers of an earlier tree that must not survive a broadcast
+            bvh.d_accel, bvh._accel_stale, bvh.d_workspace = "old repacking", False, "old workspace"
+            bvh._host_dd = {"stale": True}
+        multi_gpu.broadcast_lbvh(bvh, src=0)
+        pos, tri = syn.triangle_soup(n_tri, seed=seed)
+        _check_tree(bvh, ko.lbvh_build(pos, tri), n_tri)
+        assert bvh.d_positions.numpy().tobytes() == pos.tobytes()
+        if rank != 0:
+            assert bvh.d_accel is None and bvh._accel_stale and bvh.d_workspace is None
 
-    # ---- VDB broadcast -----------------------------------------------------------------------------------
+    # ---- VDB broadcast ------------------------------------------------------------------------------------
+    dim = (32, 64, 64)
+    vol = syn.head_volume(dim)
+    ref = ko.OracleVDB(vol, (3, 2, 2), 1, True, HEAD_TF.empty_scalar_ranges)
     vdb = DepthBoxVDB("cpu")
     if rank == 0:
         plan = _lib.VdbPlan()
-        plan.leaf_num, plan.node_num, plan.child_num, plan.atlas_map_num = 3, 4, 64, 4
-        plan.param.vox_per_atlas_brick, plan.param.root_lev = 10, 1
-        plan.atlas_voxels = 3 * 1000
-        vdb.plan, vdb.voxel_bytes = plan, 1
-        vdb.d_node_pools = torch.arange(4 * 32, dtype=torch.uint8)
-        vdb.d_child_pools = torch.arange(64, dtype=torch.int32)
-        vdb.d_atlas_brick_to_node = torch.arange(4, dtype=torch.int32)
-        vdb.d_atlas = (torch.arange(3000) % 251).to(torch.uint8)
-        vdb.device_data = _lib.VdbDeviceData()
-        vdb.rebind()
+        C.memmove(C.byref(plan.param), ref.param.tobytes(), 124)
+        plan.leaf_num, plan.node_num, plan.child_num = ref.leaf_num, len(ref.nodes), len(ref.child_pools)
+        plan.atlas_map_num, plan.atlas_voxels = len(ref.atlas_brick_to_node), ref.atlas.size
+        vdb.alloc_blob(plan, 1)
+        vdb.d_node_pools.copy_(torch.from_numpy(ref.nodes.view(np.uint8).reshape(-1)))
+        vdb.d_child_pools.copy_(torch.from_numpy(ref.child_pools.view(np.int32)))
+        vdb.d_atlas_brick_to_node.copy_(torch.from_numpy(ref.atlas_brick_to_node.view(np.int32)))
+        vdb.d_atlas.copy_(torch.from_numpy(ref.atlas.reshape(-1)))
+        vdb._complete = True
     multi_gpu.broadcast_vdb(vdb, src=0)
-    assert vdb.plan.leaf_num == 3 and vdb.plan.param.vox_per_atlas_brick == 10
-    assert vdb.GetDeviceData().atlas == vdb.d_atlas.data_ptr()
-    assert int(vdb.d_atlas.to(torch.int64).sum()) == int((torch.arange(3000) % 251).sum())
+    assert vdb.IsComplete() and vdb.plan.leaf_num == ref.leaf_num and vdb.voxel_bytes == 1
+    assert bytes(vdb.plan.param)[:124] == ref.param.tobytes()[:124]
+    dd = vdb.GetDeviceData()
+    assert dd.atlas == vdb.d_atlas.data_ptr() and dd.child_pools == vdb.d_child_pools.data_ptr()
+    assert dd.node_pools == vdb.d_node_pools.data_ptr() and dd.leaf_num == ref.leaf_num
+    assert vdb.d_atlas.numpy().tobytes() == ref.atlas.tobytes()
+    assert vdb.d_child_pools.numpy().view(np.uint32).tobytes() == ref.child_pools.tobytes()
+    assert vdb.d_node_pools.numpy().tobytes() == ref.nodes.tobytes()
 
-    # ---- stripe gather: each rank paints its own stripes, rank 0 ends up with the whole frame ----------
-    H, W = 100, 24   # 7 stripes, the last one partial
+    # ---- stripes: each rank renders its own (the checker's marcher), gathered two frames deep ---------------
+    W, H = 40, 100   # 7 stripes, the last one partial
+    g = multi_gpu.StripeGatherer(W, H, world, rank, "cpu")
     frame = torch.zeros((H, W, 4), dtype=torch.uint8)
+    assembled, want = [], []
+    for orbit in (0, 30, 60):
+        w2s, c, proj = dvr_setup(dim, (2, 1, 1), W, H, 1.0, orbit)
+        view = (w2s, cam.inverse_projective(proj), c.pos, c.rotation())
+        buf = g.begin(frame)
+        if g.frames >= 2 and rank == 0:
+            assembled.append(frame.numpy().copy())  # the frame of two submits ago has just been put together
+        for j, s in enumerate(multi_gpu.stripes_of(H, world, rank)):
+            rows = (16 * s, min(H, 16 * s + 16))
+            img = np.zeros((H, W, 4), np.uint8)
+            ko.dvr_render(ref, HEAD_TF.dat, *view, W, H, rows=rows, rgba=img)
+            buf[j, :rows[1] - rows[0]] = torch.from_numpy(img[rows[0]:rows[1]])
+        g.submit()
+        if rank == 0:
+            want.append(ko.dvr_render(ref, HEAD_TF.dat, *view, W, H)[0])
+    if rank == 0:
+        g._wait(g.slot, frame)
+        assembled.append(frame.numpy().copy())
+        g._wait(g.slot ^ 1, frame)
+        assembled.append(frame.numpy().copy())
+        assert len(assembled) == 3
+        for a, b in zip(assembled, want):
+            assert a.tobytes() == b.tobytes()
+        assert (want[0][..., 3] > 0).mean() > 0.05
+    else:
+        g.flush()
+    # the blocking form over a frame rendered in place
+    frame2 = torch.zeros((H, W, 4), dtype=torch.uint8)
     for s in multi_gpu.stripes_of(H, world, rank):
-        frame[16 * s:16 * s + 16] = 10 * (rank + 1) + s
-    scratch = multi_gpu.gather_stripes(frame, world, rank, 0)
-    multi_gpu.gather_stripes(frame, world, rank, 0, scratch)  # buffers are reused on the next frame
+        frame2[16 * s:16 * s + 16] = 10 * (rank + 1) + s
+    multi_gpu.gather_stripes(frame2, world, rank, 0)
     if rank == 0:
         for s in range(7):
-            assert int(frame[16 * s, 0, 0]) == 10 * (s % world + 1) + s
-            assert (frame[16 * s:min(H, 16 * s + 16)] == frame[16 * s, 0, 0]).all()
+            assert (frame2[16 * s:min(H, 16 * s + 16)] == 10 * (s % world + 1) + s).all()
     assert multi_gpu.split_range(10, 3, 0) == (0, 4) and multi_gpu.split_range(10, 3, 2) == (7, 10)
+    assert multi_gpu.stripes_per_rank(H, world) == _lib.lib().kk_stripes_per_rank(H, world) == 4
     dist.barrier()
     dist.destroy_process_group()
 
@@ -79,7 +154,3 @@ def test_two_rank_broadcast_and_gather(tmp_path):
     world = 2
     port = 29500 + (os.getpid() % 2000)
     mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
-    a = torch.load(os.path.join(tmp_path, "bvh0.pt"))
-    b = torch.load(os.path.join(tmp_path, "bvh1.pt"))
-    for k in a:
-        assert torch.equal(a[k], b[k]), k
