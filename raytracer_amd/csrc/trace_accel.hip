@@ -528,6 +528,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(5, 5)))
     uint32_t rayIdx = 0;
     RayState ray;
     RaySigns sg{false, false, false, 0u};          // which of min / max is the near plane; octant
+    Shear shear{};                                 // WATERTIGHT: the ray's shear, made once per ray
     uint32_t cur = 0;                              // node to visit next
     bool have = false;                             // cur is valid
     uint32_t grpBase = 0, grpBits = 0;             // current group (see above)
@@ -596,6 +597,8 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(5, 5)))
                     rayIdx = order ? order[r] : r;
                     const float *p = rays + 6ull * rayIdx;
                     prepare_ray(F3(p[0], p[1], p[2]), F3(p[3], p[4], p[5]), ray, sg, mode);
+                    if (WATERTIGHT)
+                        shear = make_shear(ray.dir);
                     nodeVisits = triTests = 0;
                     restart();
                     float tEnter, tExit;
@@ -688,7 +691,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(5, 5)))
                     dbgTriLanes += parked;
                 }
                 if (pendC != 0u) { // one triangle per lane and phase: lanes with longer runs stay parked
-                    test_run<COUNT, WATERTIGHT>(recs, nodes, parents, ray, mode, pendW, 1u, best, triTests);
+                    test_run<COUNT, WATERTIGHT>(recs, nodes, parents, ray, mode, pendW, 1u, best, triTests, shear);
                     ++pendW;
                     --pendC;
                 }

@@ -138,8 +138,14 @@ __device__ __forceinline__ Shear make_shear(f3 d) {
     s.sz = 1.f / d[s.kz];
     return s;
 }
-// returns t (< 0: miss); bx, by = weights of v1 and v2 like the reference's barycentrics
-__device__ __forceinline__ float hit_watertight(const Shear &s, f3 org, f3 v0, f3 v1, f3 v2, float &bx,
+// returns t (< 0: miss); bx, by = weights of v1 and v2 like the reference's barycentrics.
+// The edge functions decide hit or miss (that is what makes the test watertight); the distance and the
+// barycentrics of a hit are then computed with the reference's Moeller-Trumbore arithmetic (the
+// sheared-space t = (U Az + V Bz + W Cz) / det loses several digits on small triangles far from the
+// origin), so that a ray that hits the same triangle under both tests reports the same bits. Only when
+// that arithmetic cannot be used (its determinant is below its own threshold, or its t comes out
+// negative) are the sheared-space values kept.
+__device__ __forceinline__ float hit_watertight(const Shear &s, f3 org, f3 dir, f3 v0, f3 v1, f3 v2, float &bx,
                                                 float &by) {
     const f3 A = v0 - org, B = v1 - org, C = v2 - org;
     const float Ax = A[s.kx] - s.sx * A[s.kz], Ay = A[s.ky] - s.sy * A[s.kz];
@@ -164,6 +170,24 @@ __device__ __forceinline__ float hit_watertight(const Shear &s, f3 org, f3 v0, f
         return -1.f;
     bx = V * inv;
     by = W * inv;
+    { // include/cg/ray.h:52-58 -> glm intersectRayTriangle, without its range tests
+        const f3 e1 = v1 - v0, e2 = v2 - v0;
+        const f3 p = cross(dir, e2);
+        const float d = dot(e1, p);
+        if (d > FloatEps || d < -FloatEps) {
+            const f3 dist = org - v0;
+            const float u = dot(dist, p);
+            const f3 perp = cross(dist, e1);
+            const float v = dot(dir, perp);
+            const float invD = 1.f / d;
+            const float tm = dot(e2, perp) * invD;
+            if (tm >= 0.f) {
+                bx = u * invD;
+                by = v * invD;
+                return tm;
+            }
+        }
+    }
     return t;
 }
 
@@ -178,16 +202,45 @@ struct Hit8 {
     bool sure;
 };
 
+// The watertight test as it runs in the walk: the reference's Moeller-Trumbore quantities come first.
+// A ray that passes clear of the triangle's edges - by more than a bound on their rounding error - is
+// a hit or a miss under both tests, and a hit then IS the reference's hit (same t, same barycentrics).
+// Only a ray inside that thin band around an edge (or with a determinant too small for the
+// reference's test) is decided by the edge functions above, which two triangles sharing the edge
+// evaluate identically: no ray slips between them.
+__device__ __forceinline__ float hit_watertight_banded(const Shear &s, f3 org, f3 dir, f3 v0, f3 v1, f3 v2,
+                                                       float &bx, float &by) {
+    const f3 e1 = v1 - v0, e2 = v2 - v0;
+    const f3 p = cross(dir, e2);
+    const float det = dot(e1, p);
+    const f3 dist = org - v0;
+    const float u = dot(dist, p);
+    const f3 perp = cross(dist, e1);
+    const float v = dot(dir, perp);
+    const float ad = fabsf(det);
+    const float su = det < 0.f ? -u : u, sv = det < 0.f ? -v : v;
+    const float l1 = (fabsf(dist.x) + fabsf(dist.y) + fabsf(dist.z)) * (fabsf(dir.x) + fabsf(dir.y) + fabsf(dir.z)) *
+                     (fabsf(e1.x) + fabsf(e1.y) + fabsf(e1.z) + fabsf(e2.x) + fabsf(e2.y) + fabsf(e2.z));
+    const float m = 64.f * FloatEps * l1;
+    if (su < -m || sv < -m || su + sv > ad + m)
+        return -1.f; // clear of the triangle
+    if (ad > FloatEps && su > m && sv > m && su + sv < ad - m) { // clear of its edges: the reference's hit
+        const float inv = 1.f / det;
+        const float t = dot(e2, perp) * inv;
+        bx = u * inv;
+        by = v * inv;
+        return t; // (a negative t is rejected by the caller, as in the reference)
+    }
+    return hit_watertight(s, org, dir, v0, v1, v2, bx, by);
+}
+
 template <bool COUNT, bool WATERTIGHT>
 __device__ __forceinline__ void test_run(const TriRec *__restrict__ recs,
                                          const kk_lbvh_node *__restrict__ nodes,
                                          const uint32_t *__restrict__ parents, const RayState &r,
                                          uint32_t mode, uint32_t w0, uint32_t n, Hit8 &best,
-                                         uint32_t &triTests) {
+                                         uint32_t &triTests, const Shear &shear = Shear{}) {
     const Ray ray{r.pos, r.dir};
-    Shear shear{};
-    if (WATERTIGHT && n != 0u)
-        shear = make_shear(r.dir);
     for (uint32_t w = w0; w < w0 + n; ++w) {
         const uint4 *p = reinterpret_cast<const uint4 *>(recs + w);
         const uint4 a = p[0], b = p[1], c = p[2];
@@ -195,7 +248,7 @@ __device__ __forceinline__ void test_run(const TriRec *__restrict__ recs,
         const f3 v0 = F3(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z));
         const f3 v1 = F3(__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z));
         const f3 v2 = F3(__uint_as_float(c.x), __uint_as_float(c.y), __uint_as_float(c.z));
-        const float t = WATERTIGHT ? hit_watertight(shear, r.pos, v0, v1, v2, bx, by)
+        const float t = WATERTIGHT ? hit_watertight_banded(shear, r.pos, r.dir, v0, v1, v2, bx, by)
                                    : HitTriangle(ray, v0, v1, v2, bx, by);
         if (COUNT)
             ++triTests;
