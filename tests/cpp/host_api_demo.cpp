@@ -2,7 +2,12 @@
 // (app/rt_lbvh.cpp:163-296, app/dvr_dpbx_vdb.cpp:271-381), headless, and dumps the results as raw
 // binary files for tests/test_gpu_cpp_host.py to compare with the Python path and the CPU checker.
 //   host_api_demo <in_dir> <out_dir>
-// in_dir holds little-endian raw arrays written by the test (positions.f32, tri.u32, ...).
+// in_dir holds the scene as OBJ / MTL / XML text (scene.obj, ...), a RAW volume and a transfer-function
+// file, read with the host loaders of include/kouek/data/ like the applications read theirs, plus the
+// camera matrices as little-endian raw arrays written by the test.
+#include <kouek/data/mesh.h>
+#include <kouek/data/raw_volume.h>
+#include <kouek/data/transfer_function.h>
 #include <kouek/ray_caster/ray_caster.h>
 #include <kouek/ray_tracer/ray_tracer.h>
 
@@ -36,15 +41,33 @@ int main(int argc, char **argv) {
         return 1;
     }
     // ---------------- path 1: LBVH + path tracer ----------------
-    auto positions = load<vec3>(in + "/positions.f32");
-    auto normals = load<vec3>(in + "/normals.f32");
-    auto texCoords = load<vec2>(in + "/tex_coords.f32");
-    auto fpi = load<uvec3>(in + "/fpi.u32");
-    auto fni = load<uvec3>(in + "/fni.u32");
-    auto fti = load<uvec3>(in + "/fti.u32");
-    auto groups = load<uint32_t>(in + "/groups.u32");
-    auto lights = load<RayTracer::Light>(in + "/lights.bin");
-    auto materials = load<RayTracer::Material>(in + "/materials.bin");
+    // mesh, materials and lights as app/rt_lbvh.cpp:160-226 of the reference assembles them
+    Data::SceneConfig scnCfg(in + "/scene.obj");
+    if (!scnCfg.isComplete)
+        return 1;
+    Data::OBJMesh mesh(in + "/scene.obj", scnCfg.lights);
+    if (!mesh.IsComplete())
+        return 1;
+    const auto &positions = mesh.GetPositions();
+    const auto &normals = mesh.GetNormals();
+    const auto &texCoords = mesh.GetTextureCoordinates();
+    const auto &fpi = mesh.GetFacePositionIndices();
+    const auto &fni = mesh.GetFaceNormalIndices();
+    const auto &fti = mesh.GetFaceTextureCoordinateIndices();
+    const auto &groups = mesh.GetGroupStartFaceIndices();
+    std::vector<RayTracer::Light> lights;
+    for (auto &l : mesh.GetLights())
+        lights.push_back(l.type == Data::OBJMesh::Light::Type::Quad
+                             ? RayTracer::Light::CreateQuad(l.quad.o, l.quad.u, l.quad.v, l.radiance)
+                             : RayTracer::Light::CreateSphere(l.sphere.r, l.sphere.o, l.radiance));
+    std::vector<RayTracer::Material> materials(mesh.GetGroupToMaterialNames().size());
+    for (auto &[gi, name] : mesh.GetGroupToMaterialNames()) {
+        const auto &m = mesh.GetNameToMaterials().at(name);
+        auto itr = scnCfg.lights.find(name);
+        materials[gi] = itr == scnCfg.lights.end()
+                            ? RayTracer::Material::Create(m.kd, m.ks, m.tr, m.ni, m.ns)
+                            : RayTracer::Material::Create(m.kd, m.ks, m.tr, m.ni, m.ns, itr->second.radiance);
+    }
     auto cam = load<float>(in + "/camera.f32"); // proj 16, eyePos 3, eyeRot 9, W, H, spp
     auto lbvh = std::make_shared<RayTracer::LBVH>();
     lbvh->BuildFrom({positions, fpi}, out + "/lbvh.log");
@@ -82,10 +105,14 @@ int main(int argc, char **argv) {
     save(out + "/pt_spp.f32", spp);
 
     // ---------------- path 2: Depth-Box VDB + DVR ----------------
-    auto vol = load<uint8_t>(in + "/volume.u8");
     auto vdim = load<uint32_t>(in + "/volume_dim.u32"); // dx dy dz, log2Dims[3]
-    auto rngs = load<std::array<uint8_t, 2>>(in + "/empty_rngs.u8");
-    auto tf = load<vec4>(in + "/tf.f32");
+    Data::RAWVolume<uint8_t> rawVolume(in + "/volume.raw", uvec3(vdim[0], vdim[1], vdim[2]));
+    Data::TransferFunction<uint8_t, 0, 255> tfFile(in + "/tf.txt");
+    if (!rawVolume.IsComplete() || !tfFile.IsComplete())
+        return 1;
+    const auto &vol = rawVolume.Get();
+    const auto &rngs = tfFile.GetEmptyScalarRanges();
+    const auto &tf = tfFile.Get();
     auto dcam = load<float>(in + "/dvr_camera.f32"); // w2s 16, proj 16, eyePos 3, eyeRot 9, W, H
     HIP::Volume<uint8_t> volume(vol, vdim[0], vdim[1], vdim[2]);
     auto vdb = std::make_shared<RayCaster::DepthBoxVDB>();

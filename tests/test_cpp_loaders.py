@@ -1,0 +1,132 @@
+"""The header-only C++ host loaders (include/kouek/data/{mesh,raw_volume,transfer_function}.h, following
+include/data/*.h and app/rt_lbvh.cpp:60-146 of the reference) read what the Python loaders read, and for
+the reference's scene exactly the committed arrays (tests/golden/veach_mis.npz): the scene is written
+back out as OBJ / MTL / XML text from those arrays (%.9g keeps every float32), so the test needs no file
+of the reference."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from raytracer_amd import ray_tracer as rt
+from raytracer_amd.data.mesh import OBJMesh, parse_scene_xml
+from raytracer_amd.data.raw_volume import RAWVolume
+from raytracer_amd.data.scene_setup import load_obj_scene, veach_arrays
+from raytracer_amd.data.transfer_function import README_HEAD_TF, TransferFunction
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "tests", "cpp", "bin", "loaders_check")
+
+
+def write_scene(d, folder, name="scene"):
+    """OBJ + MTL + XML of the scene arrays `d` (the layout of tests/golden/veach_mis.npz)."""
+    g = lambda v: " ".join("%.9g" % float(x) for x in v)
+    gs = d["grp_start_face_indices"].tolist() + [d["face_position_indices"].shape[0]]
+    lit = [i for i in range(len(gs) - 1) if (d["mat_emission"][i] != 0).any()]
+    with open(os.path.join(folder, name + ".obj"), "w") as f:
+        f.write(f"mtllib {name}.mtl\n\n")
+        for v in d["positions"]:
+            f.write("v " + g(v) + "\n")
+        for v in d["normals"]:
+            f.write("vn " + g(v) + "\n")
+        for v in d["tex_coords"]:
+            f.write("vt " + g(v) + "\n")
+        for gi in range(len(gs) - 1):
+            f.write(f"g group{gi}\nusemtl mtl{gi}\n")
+            for fi in range(gs[gi], gs[gi + 1]):
+                p, t, n = (d[k][fi] + 1 for k in ("face_position_indices", "face_tex_coord_indices",
+                                                  "face_normal_indices"))
+                f.write("f " + " ".join(f"{p[i]}/{t[i]}/{n[i]}" for i in range(3)) + "\n")
+    with open(os.path.join(folder, name + ".mtl"), "w") as f:
+        for gi in range(len(gs) - 1):
+            f.write(f"newmtl mtl{gi}\nKd {g(d['mat_kd'][gi])}\nKs {g(d['mat_ks'][gi])}\n"
+                    f"Tr {g(d['mat_tr'][gi])}\nNi {g([d['mat_ni'][gi]])}\nNs {g([d['mat_ns'][gi]])}\n\n")
+    with open(os.path.join(folder, name + ".xml"), "w") as f:
+        f.write('<?xml version="1.0" encoding="utf-8"?>\n')
+        f.write(f'<camera type="perspective" width="{int(d["cam_size"][0])}" height="{int(d["cam_size"][1])}" fovy="20">\n')
+        for tag, key in (("eye", "cam_eye"), ("lookat", "cam_lookat"), ("up", "cam_up")):
+            x, y, z = ("%.9g" % float(v) for v in d[key])
+            f.write(f'\t<{tag} x="{x}" y="{y}" z="{z}"/>\n')
+        f.write("</camera>\n")
+        for gi in lit:
+            r = ",".join("%.9g" % float(v) for v in d["mat_emission"][gi])
+            f.write(f'<light mtlname="mtl{gi}" type="Sphere" radiance="{r}"/>\n')
+    return os.path.join(folder, name + ".obj")
+
+
+def _run(tmp_path, obj, vol, dim, tr, tf_text):
+    if not os.path.exists(EXE):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cpp"), "-s"])
+    vol_path, tf_path = tmp_path / "vol.raw", tmp_path / "tf.txt"
+    vol.tofile(vol_path)
+    tf_path.write_text(tf_text)
+    out = tmp_path / "out"
+    out.mkdir()
+    r = subprocess.run([EXE, obj, str(vol_path), *map(str, dim), *map(str, tr), str(tf_path), str(out)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, (r.returncode, r.stderr)
+    assert "Parameter trAxis is invalid" in r.stderr  # the refused (1, 1, 3) transform
+    return out, vol_path, tf_path
+
+
+def test_cpp_loaders_read_the_reference_scene_like_the_committed_arrays(veach, tmp_path):
+    obj = write_scene(veach, str(tmp_path))
+    rng = np.random.default_rng(3)
+    dim, tr = (7, 5, 6), (-3, 1, -2)
+    vol = rng.integers(0, 256, dim[0] * dim[1] * dim[2], dtype=np.uint8)
+    out, vol_path, tf_path = _run(tmp_path, obj, vol, dim, tr, README_HEAD_TF)
+    rd = lambda name, dt: np.fromfile(out / name, dt)
+    # mesh: the committed arrays, bit for bit
+    for name, key in (("positions.f32", "positions"), ("normals.f32", "normals"), ("tex_coords.f32", "tex_coords")):
+        assert rd(name, np.float32).tobytes() == veach[key].tobytes(), name
+    for name, key in (("fpi.u32", "face_position_indices"), ("fni.u32", "face_normal_indices"),
+                      ("fti.u32", "face_tex_coord_indices"), ("groups.u32", "grp_start_face_indices")):
+        assert rd(name, np.uint32).tobytes() == veach[key].tobytes(), name
+    # lights and materials: the structs the path tracer takes (sphere lights from the groups' vertices)
+    arr = veach_arrays(veach)
+    assert rd("lights.bin", np.uint8).tobytes() == arr["lights"].tobytes()
+    assert rd("materials.bin", np.uint8).tobytes() == arr["materials"].tobytes()
+    cam = rd("camera.f32", np.float32)
+    np.testing.assert_array_equal(cam[:3], veach["cam_eye"])
+    np.testing.assert_array_equal(cam[3:6], veach["cam_lookat"])
+    np.testing.assert_array_equal(cam[6:9], veach["cam_up"])
+    assert cam[9:].tolist() == veach["cam_size"].tolist()
+    # the Python loaders read the same files the same way
+    scn = parse_scene_xml(obj[:-4] + ".xml")
+    m = OBJMesh(obj, scn["lights"])
+    assert m.is_complete and len(m.lights) == 3
+    d2 = load_obj_scene(obj)
+    arr2 = veach_arrays(d2)
+    assert arr2["lights"].tobytes() == arr["lights"].tobytes()
+    assert arr2["materials"].tobytes() == arr["materials"].tobytes()
+    # RAW volume with an axis transform, transfer function, grid mesh
+    pv = RAWVolume(str(vol_path), dim, tr)
+    assert pv.IsComplete()
+    assert rd("volume_dim.u32", np.uint32).tolist() == list(pv.GetDimension())
+    assert rd("volume.u8", np.uint8).tobytes() == pv.dat.tobytes()
+    tf = TransferFunction(README_HEAD_TF)
+    assert rd("tf.f32", np.float32).tobytes() == tf.dat.tobytes()
+    assert rd("tf_empty.u8", np.uint8).tolist() == tf.empty_scalar_ranges.reshape(-1).tolist() == [0, 49]
+    from raytracer_amd import synthetic as syn
+    gp, _ = syn.grid_test_mesh((3, 5, 7))
+    assert rd("grid_positions.f32", np.float32).tobytes() == gp.tobytes()
+
+
+def test_cpp_obj_loader_refuses_what_the_reference_refuses(veach, tmp_path):
+    obj = write_scene(veach, str(tmp_path))
+    text = open(obj).read()
+    for bad in ("s off\n", "f 1/1 2/2 3/3\n", "v 1 2\n"):
+        p = tmp_path / "bad.obj"
+        p.write_text(text + bad)
+        for ext in (".mtl", ".xml"):
+            (tmp_path / ("bad" + ext)).write_text(open(obj[:-4] + ext).read())
+        p.write_text(p.read_text().replace("mtllib scene.mtl", "mtllib bad.mtl"))
+        vol = np.zeros(8, np.uint8)
+        (tmp_path / "v.raw").write_bytes(vol.tobytes())
+        (tmp_path / "t.txt").write_text(README_HEAD_TF)
+        (tmp_path / "o").mkdir(exist_ok=True)
+        r = subprocess.run([EXE, str(p), str(tmp_path / "v.raw"), "2", "2", "2", "1", "2", "3",
+                            str(tmp_path / "t.txt"), str(tmp_path / "o")], capture_output=True, text=True)
+        assert r.returncode == 4 and "Failed parsing line" in r.stderr, (bad, r.returncode, r.stderr)
+        assert not OBJMesh(str(p), {}).is_complete

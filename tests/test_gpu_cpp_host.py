@@ -42,15 +42,9 @@ def test_cpp_host_classes_match_checker(oracle, veach, tmp_path):
     arr = veach_arrays(veach)
     W, H, spp = 96, 64, 2
     c, proj = veach_camera(veach, W, H)
-    veach["positions"].astype(np.float32).tofile(ind / "positions.f32")
-    veach["normals"].astype(np.float32).tofile(ind / "normals.f32")
-    veach["tex_coords"].astype(np.float32).tofile(ind / "tex_coords.f32")
-    veach["face_position_indices"].astype(np.uint32).tofile(ind / "fpi.u32")
-    veach["face_normal_indices"].astype(np.uint32).tofile(ind / "fni.u32")
-    veach["face_tex_coord_indices"].astype(np.uint32).tofile(ind / "fti.u32")
-    veach["grp_start_face_indices"].astype(np.uint32).tofile(ind / "groups.u32")
-    arr["lights"].tofile(ind / "lights.bin")
-    arr["materials"].tofile(ind / "materials.bin")
+    # the scene goes in as OBJ / MTL / XML text: the program reads it with the C++ host loaders
+    from test_cpp_loaders import write_scene
+    write_scene(veach, str(ind))
     np.concatenate([proj.reshape(-1), c.pos, c.rotation().reshape(-1),
                     [W, H, spp]]).astype(np.float32).tofile(ind / "camera.f32")
     # volume path
@@ -58,10 +52,10 @@ def test_cpp_host_classes_match_checker(oracle, veach, tmp_path):
     dim = (64, 128, 128)
     vol = syn.head_volume(dim)
     l2 = (4, 3, 3)
-    vol.tofile(ind / "volume.u8")
+    vol.tofile(ind / "volume.raw")
     np.array([dim[0], dim[1], dim[2], *l2], np.uint32).tofile(ind / "volume_dim.u32")
-    HEAD_TF.empty_scalar_ranges.astype(np.uint8).tofile(ind / "empty_rngs.u8")
-    HEAD_TF.dat.astype(np.float32).tofile(ind / "tf.f32")
+    from raytracer_amd.data.transfer_function import README_HEAD_TF
+    (ind / "tf.txt").write_text(README_HEAD_TF)
     DW, DH = 120, 90
     w2s, dc, dproj = dvr_setup(dim, (2, 1, 1), DW, DH, orbit_steps=33)
     np.concatenate([w2s.reshape(-1), dproj.reshape(-1), dc.pos, dc.rotation().reshape(-1),
