@@ -472,9 +472,11 @@ constexpr int LDS_DEPTH = 20;   // entries kept in LDS; deeper ones (rare) live 
 constexpr int REFILL_BELOW = 32;
 constexpr int PARK_MIN = 16; // run the triangle code once this many lanes wait for it ...
 constexpr int STEP_MIN = 24; // ... or fewer than this many lanes can still step
-constexpr uint32_t MAX_GRID = 1280; // 30 KB of LDS and < 96 VGPRs: five workgroups per CU
+constexpr uint32_t MAX_GRID = 1280; // most workgroups the spill area is made for (five per CU on 256 CUs)
+constexpr uint32_t GROUPS_PER_CU = 5; // 30 KB of LDS and < 96 VGPRs: five resident workgroups per CU
 __device__ __forceinline__ float4 ld4(const char *p) { return *reinterpret_cast<const float4 *>(p); }
-constexpr uint32_t QUEUES = 8;        // XCDs of the device
+constexpr uint32_t QUEUES = 8;        // ray queues (one per XCD of an MI355X; a wave starts at queue
+                                      // XCC_ID % QUEUES and moves on when it is used up, so any XCD count works)
 constexpr uint32_t QUEUE_STRIDE = 32; // counters 128 bytes apart
 // which XCD this wave runs on (hardware register XCC_ID, bits 3:0)
 __device__ __forceinline__ uint32_t xcc_id() { return __builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xfu; }
@@ -918,6 +920,9 @@ extern "C" int kk_closest_hit_accel(const void *d_accel, uint32_t face_num,
         order = (KEY_PASSES & 1) ? valsB : valsA;
     }
     uint32_t grid = div_up(ray_num, THREADS);
+    const uint32_t resident = GROUPS_PER_CU * static_cast<uint32_t>(device_cu_count());
+    if (grid > resident)
+        grid = resident;
     if (grid > MAX_GRID)
         grid = MAX_GRID;
     uint2 *spill = reinterpret_cast<uint2 *>(b + w.spill);

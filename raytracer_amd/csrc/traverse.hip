@@ -130,10 +130,11 @@ extern "C" int kk_closest_hit(const kk_lbvh_device_data *d_lbvh, const float *d_
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     uint32_t *rayCounter = static_cast<uint32_t *>(d_workspace);
     KK_HIP_TRY(hipMemsetAsync(rayCounter, 0, 256, stream));
-    // 4 workgroups per CU on 256 CUs; fewer when there are not enough rays to feed them
+    // 4 resident workgroups per CU; fewer when there are not enough rays to feed them
     uint32_t grid = div_up(ray_num, THREADS);
-    if (grid > 1024u)
-        grid = 1024u;
+    const uint32_t resident = 4u * static_cast<uint32_t>(device_cu_count());
+    if (grid > resident)
+        grid = resident;
     if (d_counters)
         closest_hit_kernel<true><<<grid, THREADS, 0, stream>>>(d_lbvh, d_positions, d_face_pos_idx,
                                                                d_rays, ray_num, d_t, d_bary, d_prim,
