@@ -351,10 +351,11 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(5, 5)))
 // paths idle. Here a grid of resident wave64 workgroups pulls pixels from a queue (8 x 8 pixel tiles in
 // row-major tile order) and every lane is a small state machine over the rays of its path:
 //   walking a closest-hit ray | walking a shadow ray | walk over, to be shaded | idle.
-// The wave alternates between two phases. Walk: every lane with a ray does one step per pass (visit
-// one record, or test one triangle of the last visit's run), the per-lane sequence of closest_hit_lane /
-// occluded_lane; a run of COOP_MIN or more triangles is tested by the whole wave for the lane that owns
-// it, so one long leaf does not hold 63 lanes up. Shade: when no lane walks any more, every lane
+// The wave alternates between two phases. Walk: in every pass each lane with a ray and no triangles
+// pending visits one record, then the triangles all those visits left pending are tested as one pool, 64
+// (ray, triangle) pairs at a time whichever lanes they belong to - a lane ends up with the hit of the
+// per-lane sequence of closest_hit_lane / occluded_lane, and neither a long leaf nor a pass with few
+// lanes at triangles costs the wave a pass per triangle. Shade: when no lane walks any more, every lane
 // consumes its walk's result (hit -> material, normal; shadow answer -> add the light), samples lights
 // until one needs a shadow ray, or samples the path's next direction, and lanes whose path ended write
 // their pixel and take the next pixels of the queue with one ballot + one atomic per wave - so each
@@ -377,8 +378,6 @@ enum : uint32_t {
 #ifndef KK_PT_WAVES
 #define KK_PT_WAVES 4 // resident waves per SIMD = workgroups per CU
 #endif
-constexpr int WALK_FIRST = 1;  // leave the walk loop for shading once fewer lanes than this walk while others wait
-constexpr int COOP_MIN = 8;    // a leaf run of at least this many triangles is tested by the whole wave
 constexpr uint32_t COUNTER_SLOTS = 64;
 // Queue heads of the launches in flight: a launch takes the next slot and clears it on its stream
 // first. (Launches more than COUNTER_SLOTS apart share a slot; they cannot overlap unless that many
@@ -404,6 +403,28 @@ __device__ __forceinline__ bool final_hit_passes(const kk_lbvh_node *__restrict_
     return accel::passes_parent(nodes, b.w, ray);
 }
 
+// Inclusive prefix sum / running maximum over the 64 lanes of a wave with data-parallel-primitive moves:
+// four shifts inside each row of 16 lanes, then the last lane of a row into the rows after it.
+__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v) {
+    v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x111, 0xf, 0xf, false));
+    v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x112, 0xf, 0xf, false));
+    v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x114, 0xf, 0xf, false));
+    v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x118, 0xf, 0xf, false));
+    v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x142, 0xa, 0xf, false));
+    v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x143, 0xc, 0xf, false));
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_inclusive_max(uint32_t v) {
+    auto mx = [](uint32_t a, int b) { return a > static_cast<uint32_t>(b) ? a : static_cast<uint32_t>(b); };
+    v = mx(v, __builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x111, 0xf, 0xf, false));
+    v = mx(v, __builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x112, 0xf, 0xf, false));
+    v = mx(v, __builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x114, 0xf, 0xf, false));
+    v = mx(v, __builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x118, 0xf, 0xf, false));
+    v = mx(v, __builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x142, 0xa, 0xf, false));
+    v = mx(v, __builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x143, 0xc, 0xf, false));
+    return v;
+}
+
 struct PathState {
     // the path
     uint32_t pixel;  // y * W + x
@@ -421,11 +442,13 @@ template <bool COUNT>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(KK_PT_WAVES, KK_PT_WAVES))) void path_trace_persistent_kernel(
     const accel::View view, const kk_pt_scene p, const kk_pt_frame f, float *__restrict__ accum,
     uint8_t *__restrict__ rgba, int W, int H, int y0, int y1, float sampleIdx, uint32_t seed,
-    uint32_t *pixelQueue, unsigned long long *counters, int walkFirst, int coopMin) {
+    uint32_t *pixelQueue, unsigned long long *counters) {
     using namespace persist;
     using namespace accel;
     __shared__ uint32_t s_stack[LANE_LDS_DEPTH * THREADS];
     __shared__ unsigned short s_bits[LANE_LDS_DEPTH * THREADS];
+    __shared__ unsigned long long s_key[THREADS]; // pooled triangle test: an owner's best (t, sorted position) ...
+    __shared__ uint32_t s_mark[THREADS];          // ... and which lane's triangles start at a pair
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const unsigned long long lanesBelow = (1ull << lane) - 1ull;
@@ -455,7 +478,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(KK_PT_W
     Hit8 best{};
 
     unsigned long long cntPasses = 0, cntWalkLanes = 0, cntShades = 0, cntShadeLanes = 0, cntRays = 0,
-                       cntVisits = 0, cntTris = 0;
+                       cntVisits = 0, cntTris = 0, cntRounds = 0, cntPairs = 0, cntExact = 0;
     // a new ray for this lane: `closest` walks for the nearest hit, else for any hit nearer than tMax
     auto start_ray = [&](f3 pos, f3 dir, bool closest, float tMax) {
         if (COUNT)
@@ -515,7 +538,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(KK_PT_W
         }
 
     };
-    long long tcLoop = 0, tcV = 0, tcT = 0, tcCoop = 0, tcLights = 0, tcBounce = 0, tcEnd = 0, tc0 = 0, tc1 = 0;
+    long long tcLoop = 0, tcV = 0, tcT = 0, tcLights = 0, tcBounce = 0, tcEnd = 0, tc0 = 0, tc1 = 0;
     auto lap = [&](long long &acc) {
         if (COUNT) {
             tc1 = clock64();
@@ -529,8 +552,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(KK_PT_W
         // ================= walk: one step per lane and pass until no lane has a ray ====================
         while (true) {
             const int nWalk = __popcll(__ballot(stage == ST_WALK_C || stage == ST_WALK_S));
-            // leave when no lane walks, or when few still do while others wait to be shaded
-            if (nWalk == 0 || (nWalk < walkFirst && __ballot(stage >= ST_DONE_C || (stage == ST_IDLE && !poolEmpty)) != 0ull))
+            if (nWalk == 0)
                 break;
             if (COUNT) {
                 ++cntPasses;
@@ -560,118 +582,111 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(KK_PT_W
                         pendW = vis.leafW;
                         pendC = vis.leafC;
                         w.enter(st, deep, vis, sg.oct);
-                        if (COUNT)
+                        if (COUNT) {
                             ++cntVisits;
+                            if (!(vis.flags & (LONG_RUN | HUGE_RUN))) {
+                                for (int sl = 0; sl < 8; ++sl)
+                                    if ((vis.leafHits >> sl) & 1u)
+                                        cntExact += (vis.counts >> (4 * sl)) & 0xfu;
+                            } else
+                                cntExact += vis.leafC;
+                        }
                     }
                 }
                 lap(tcV);
-                if (pendC != 0u && pendC < static_cast<uint32_t>(coopMin) &&
-                    (stage == ST_WALK_C || stage == ST_WALK_S)) {
-                    if (COUNT)
-                        ++cntTris;
-                    const uint4 *tp = reinterpret_cast<const uint4 *>(view.recs + pendW);
-                    const uint4 a = tp[0], b = tp[1], c = tp[2];
-                    const f3 v0 = F3(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z));
-                    const f3 v1 = F3(__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z));
-                    const f3 v2 = F3(__uint_as_float(c.x), __uint_as_float(c.y), __uint_as_float(c.z));
-                    float bx = 0.f, by = 0.f;
-                    const float t = HitTriangle(Ray{ray.pos, ray.dir}, v0, v1, v2, bx, by);
-                    const bool isClosest = stage == ST_WALK_C;
-                    if (t >= 0.f && (t < best.t || (isClosest && t == best.t && c.w < best.k))) {
-                        if (mode == MODE_FAST || (mode == MODE_CAREFUL ? passes_parent(nodes, b.w, ray)
-                                                                       : passes_chain(nodes, view.parents, b.w, ray))) {
-                            if (isClosest) {
-                                best.t = t;
-                                best.bx = bx;
-                                best.by = by;
-                                best.fi = a.w;
-                                best.k = c.w;
-                                best.w = pendW;
-                            } else
-                                stage = ST_DONE_S_HIT;
-                        }
-                    }
-                    ++pendW;
-                    --pendC;
-                }
             }
-            lap(tcT);
-            // A long run of triangles (a leaf of many faces with one Morton code) would keep its lane
-            // walking long after the others: the whole wave tests it, 64 triangles at a time, for the
-            // lane that owns it. The owner ends up with the hit its own one-by-one loop would keep: the
-            // smallest (t, sorted position) among the triangles that are hit and accepted.
-            unsigned long long coop = __ballot((stage == ST_WALK_C || stage == ST_WALK_S) &&
-                                               pendC >= static_cast<uint32_t>(coopMin));
-            while (coop != 0ull) {
-                const int o = __ffsll(static_cast<long long>(coop)) - 1;
-                auto bcF = [&](float v) { return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), o)); };
-                auto bcU = [&](uint32_t v) { return static_cast<uint32_t>(__builtin_amdgcn_readlane(v, o)); };
+            // The triangles the lanes' last visits left pending are tested as one pool, 64 (ray,
+            // triangle) pairs at a time: pair i belongs to the first lane whose running total of
+            // pending triangles exceeds i, is tested by lane i with that lane's ray, and the owner ends
+            // up with what its own one-by-one loop would keep - the smallest (t, sorted position) among
+            // its triangles that are hit, nearer than its best and accepted. One long leaf or a few
+            // lanes with work do not hold the other lanes up for a pass per triangle.
+            while (true) {
+                const bool walking = stage == ST_WALK_C || stage == ST_WALK_S;
+                const uint32_t c = walking ? (pendC < 64u ? pendC : 64u) : 0u;
+                if (__ballot(c != 0u) == 0ull)
+                    break;
+                const uint32_t incl = wave_inclusive_sum(c);
+                const uint32_t start = incl - c;
+                const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
+                if (COUNT) {
+                    ++cntRounds;
+                    cntPairs += total < 64u ? total : 64u;
+                }
+                // owner of pair i = the last lane whose first pair is at or before i: every owner marks
+                // its first pair, a running maximum over the pairs spreads the marks
+                s_mark[tid] = 0u;
+                s_key[tid] = ~0ull;
+                __builtin_amdgcn_wave_barrier();
+                if (c != 0u && start < 64u)
+                    s_mark[(tid & ~63) + start] = static_cast<uint32_t>(lane);
+                __builtin_amdgcn_wave_barrier();
+                const bool pairOn = static_cast<uint32_t>(lane) < total;
+                const int own = static_cast<int>(wave_inclusive_max(s_mark[tid]));
+                auto fromF = [&](float v) { return __shfl(v, own, 64); };
+                auto fromU = [&](uint32_t v) { return static_cast<uint32_t>(__shfl(static_cast<int>(v), own, 64)); };
                 RayState oray;
-                oray.pos = F3(bcF(ray.pos.x), bcF(ray.pos.y), bcF(ray.pos.z));
-                oray.dir = F3(bcF(ray.dir.x), bcF(ray.dir.y), bcF(ray.dir.z));
-                oray.inv = F3(bcF(ray.inv.x), bcF(ray.inv.y), bcF(ray.inv.z));
-                const uint32_t oW = bcU(pendW), oC = bcU(pendC), oMode = bcU(mode);
-                const bool oClosest = bcU(stage) == ST_WALK_C;
-                const float oT = bcF(best.t);
-                const uint32_t oK = bcU(best.k);
-                const uint32_t n = oC < 64u ? oC : 64u;
-                bool cand = false;
+                oray.pos = F3(fromF(ray.pos.x), fromF(ray.pos.y), fromF(ray.pos.z));
+                oray.dir = F3(fromF(ray.dir.x), fromF(ray.dir.y), fromF(ray.dir.z));
+                const float oT = fromF(best.t);
+                const uint32_t oK = fromU(best.k);
+                const uint32_t rec = fromU(pendW - start) + static_cast<uint32_t>(lane);
+                const uint32_t oModeStage = fromU(mode | (stage << 8));
+                const uint32_t oMode = oModeStage & 0xffu;
+                const bool oClosest = (oModeStage >> 8) == ST_WALK_C;
+                unsigned long long key = ~0ull;
                 float t = 0.f, bx = 0.f, by = 0.f;
-                uint32_t fi = 0u, k = 0u;
-                if (static_cast<uint32_t>(lane) < n) {
-                    const uint4 *tp = reinterpret_cast<const uint4 *>(view.recs + oW + lane);
-                    const uint4 a = tp[0], b = tp[1], c = tp[2];
+                uint32_t fi = 0u;
+                if (pairOn) {
+                    const uint4 *tp = reinterpret_cast<const uint4 *>(view.recs + rec);
+                    const uint4 a = tp[0], b = tp[1], cc = tp[2];
                     const f3 v0 = F3(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z));
                     const f3 v1 = F3(__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z));
-                    const f3 v2 = F3(__uint_as_float(c.x), __uint_as_float(c.y), __uint_as_float(c.z));
+                    const f3 v2 = F3(__uint_as_float(cc.x), __uint_as_float(cc.y), __uint_as_float(cc.z));
                     t = HitTriangle(Ray{oray.pos, oray.dir}, v0, v1, v2, bx, by);
                     fi = a.w;
-                    k = c.w;
-                    cand = t >= 0.f && (t < oT || (oClosest && t == oT && k < oK));
-                    if (cand && oMode != MODE_FAST)
+                    bool cand = t >= 0.f && (t < oT || (oClosest && t == oT && cc.w < oK));
+                    if (cand && oMode != MODE_FAST) {
+                        oray.inv = 1.f / oray.dir; // (a ray with a zero component is in MODE_CHAIN, which divides)
                         cand = oMode == MODE_CAREFUL ? passes_parent(nodes, b.w, oray)
                                                      : passes_chain(nodes, view.parents, b.w, oray);
-                }
-                if (COUNT && lane == o)
-                    cntTris += n;
-                const unsigned long long cm = __ballot(cand);
-                if (cm != 0ull) {
-                    if (!oClosest) {
-                        if (lane == o)
-                            stage = ST_DONE_S_HIT;
-                    } else {
+                    }
+                    if (cand) {
                         // t >= 0: its bits order like the value ("+ 0" turns -0 into +0)
-                        unsigned long long key =
-                            cand ? (static_cast<unsigned long long>(__float_as_uint(t + 0.f)) << 32) | k : ~0ull;
-                        unsigned long long m = key;
-                        for (int off = 32; off > 0; off >>= 1) {
-                            const unsigned long long other = __shfl_xor(m, off, 64);
-                            m = other < m ? other : m;
-                        }
-                        const int win = __ffsll(static_cast<long long>(__ballot(cand && key == m))) - 1;
-                        const float wt = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(t), win));
-                        const float wbx = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(bx), win));
-                        const float wby = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(by), win));
-                        const uint32_t wfi = __builtin_amdgcn_readlane(fi, win);
-                        const uint32_t wk = __builtin_amdgcn_readlane(k, win);
-                        if (lane == o) {
-                            best.t = wt;
-                            best.bx = wbx;
-                            best.by = wby;
-                            best.fi = wfi;
-                            best.k = wk;
-                            best.w = oW + static_cast<uint32_t>(win);
-                        }
+                        key = (static_cast<unsigned long long>(__float_as_uint(t + 0.f)) << 32) | cc.w;
+                        atomicMin(&s_key[(tid & ~63) + own], key);
                     }
                 }
-                if (lane == o) {
-                    pendW += n;
-                    pendC -= n;
+                const uint32_t served = (incl < 64u ? incl : 64u) - (start < 64u ? start : 64u);
+                if (COUNT)
+                    cntTris += served;
+                pendW += served;
+                pendC -= served;
+                if (__ballot(key != ~0ull) == 0ull)
+                    continue; // no pair of this round is a hit its owner would take
+                __builtin_amdgcn_wave_barrier();
+                // the owner's winning pair hands over its hit
+                const unsigned long long winners = __ballot(key != ~0ull && s_key[(tid & ~63) + own] == key);
+                const unsigned long long mine = served == 0u ? 0ull : ((served == 64u ? ~0ull : ((1ull << served) - 1ull)) << (start & 63u));
+                const int win = __ffsll(static_cast<long long>(winners & mine)) - 1;
+                const int src = win < 0 ? lane : win;
+                const float wt = __shfl(t, src, 64), wbx = __shfl(bx, src, 64), wby = __shfl(by, src, 64);
+                const uint32_t wfi = static_cast<uint32_t>(__shfl(static_cast<int>(fi), src, 64));
+                if (win >= 0) {
+                    if (stage == ST_WALK_S)
+                        stage = ST_DONE_S_HIT;
+                    else {
+                        best.t = wt;
+                        best.bx = wbx;
+                        best.by = wby;
+                        best.fi = wfi;
+                        best.k = static_cast<uint32_t>(s_key[tid]);
+                        best.w = pendW - served + (static_cast<uint32_t>(win) - start);
+                    }
                 }
-                coop = __ballot((stage == ST_WALK_C || stage == ST_WALK_S) &&
-                                pendC >= static_cast<uint32_t>(coopMin));
+                __builtin_amdgcn_wave_barrier();
             }
-            lap(tcCoop);
+            lap(tcT);
         }
         lap(tcLoop);
         if (__ballot(stage != ST_IDLE) == 0ull && poolEmpty)
@@ -843,7 +858,6 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(KK_PT_W
             atomicAdd(&counters[8], static_cast<unsigned long long>(tcLoop));
             atomicAdd(&counters[9], static_cast<unsigned long long>(tcV));
             atomicAdd(&counters[10], static_cast<unsigned long long>(tcT));
-            atomicAdd(&counters[14], static_cast<unsigned long long>(tcCoop));
             atomicAdd(&counters[11], static_cast<unsigned long long>(tcLights));
             atomicAdd(&counters[12], static_cast<unsigned long long>(tcBounce));
             atomicAdd(&counters[13], static_cast<unsigned long long>(tcEnd));
@@ -854,6 +868,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(KK_PT_W
             cntRays += __shfl_xor(cntRays, o, 64);
             cntVisits += __shfl_xor(cntVisits, o, 64);
             cntTris += __shfl_xor(cntTris, o, 64);
+            cntExact += __shfl_xor(cntExact, o, 64);
         }
         if (lane == 0) {
             atomicAdd(&counters[0], cntPasses);
@@ -863,6 +878,9 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(KK_PT_W
             atomicAdd(&counters[4], cntRays);
             atomicAdd(&counters[5], cntVisits);
             atomicAdd(&counters[6], cntTris);
+            atomicAdd(&counters[14], cntExact); // triangles of the hit leaf slots alone
+            atomicAdd(&counters[7], cntRounds); // rounds of the pooled triangle test (per wave) ...
+            atomicAdd(&counters[15], cntPairs); // ... and the pairs tested in them
         }
     }
 }
@@ -937,17 +955,14 @@ extern "C" int kk_pt_render_sample(const kk_lbvh_device_data *d_lbvh, const kk_p
         const uint32_t resident = KK_PT_WAVES * static_cast<uint32_t>(device_cu_count());
         if (pgrid > resident)
             pgrid = resident;
-        const int walkFirst = persist::WALK_FIRST;
-        const int coopMin = persist::COOP_MIN;
         unsigned long long *dbg = g_debugCounters.load();
         if (dbg)
             path_trace_persistent_kernel<true><<<pgrid, THREADS, 0, stream>>>(
-                view, *h_scene, *h_frame, d_accum, d_rgba, width, height, y0, y1, sample_index, seed, head, dbg,
-                walkFirst, coopMin);
+                view, *h_scene, *h_frame, d_accum, d_rgba, width, height, y0, y1, sample_index, seed, head, dbg);
         else
             path_trace_persistent_kernel<false><<<pgrid, THREADS, 0, stream>>>(
                 view, *h_scene, *h_frame, d_accum, d_rgba, width, height, y0, y1, sample_index, seed, head,
-                nullptr, walkFirst, coopMin);
+                nullptr);
     } else
         path_trace_kernel<false><<<grid, THREADS, 0, static_cast<hipStream_t>(stream_)>>>(
             d_lbvh, accel::View{}, *h_scene, *h_frame, d_accum, d_rgba, width, height, y0, y1, sample_index,

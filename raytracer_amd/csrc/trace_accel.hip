@@ -59,19 +59,33 @@ struct alignas(256) BuildCtl {
     uint32_t bounds[MAX_LEVELS + 2]; // wide nodes of level l are [bounds[l], bounds[l + 1])
 };
 
+// A leaf of the LBVH is a run of triangles with one Morton code; in a scene whose triangles are small
+// against the 1/1024 grid such runs are long (dozens of faces), and a ray that touches the leaf's box
+// would test them all. A run of SPLIT_MIN..SPLIT_MAX triangles therefore gets a wide node of its own
+// (a "run node"): its triangles, ordered along the longest axis of their centres, in up to eight chunks
+// with a box each. Which triangles are candidates is unchanged (every triangle still carries its
+// leaf's parent for the acceptance test); fewer of them are met.
+constexpr uint32_t SPLIT_MIN = 4, SPLIT_MAX = 120; // 8 chunks of at most 15 (the count nibbles)
+constexpr uint32_t RUN_FLAG = 0x40000000u;          // rootOf: low bits = leaf index instead of a binary node
+
 struct Layout {
-    size_t header, ctl, nodes, tris, parents, rootOf, recSrc, total;
+    size_t header, ctl, nodes, tris, parents, rootOf, leafParent, recSrc, total;
+    uint32_t wideMax;
 };
 inline Layout layout(uint32_t faceNum, uint32_t compactedNum) {
     Layout l;
     Carver c;
     const uint32_t nodeNum = compactedNum > 1 ? compactedNum - 1 : 1;
+    // a wide node over binary nodes has >= 2 slots: at most nodeNum of them; a leaf with a run node has
+    // >= SPLIT_MIN - 1 triangles beyond its first: at most (N - M) / (SPLIT_MIN - 1) of those
+    l.wideMax = nodeNum + (faceNum - compactedNum) / (SPLIT_MIN - 1) + 1;
     l.header = c.take(sizeof(Header));
     l.ctl = c.take(sizeof(BuildCtl));
-    l.nodes = c.take(sizeof(Wide8) * static_cast<size_t>(nodeNum)); // a wide node has >= 2 slots
+    l.nodes = c.take(sizeof(Wide8) * static_cast<size_t>(l.wideMax));
     l.tris = c.take(sizeof(TriRec) * static_cast<size_t>(faceNum));
     l.parents = c.take(sizeof(uint32_t) * static_cast<size_t>(nodeNum)); // parent of each binary node
-    l.rootOf = c.take(sizeof(uint32_t) * static_cast<size_t>(nodeNum));  // binary root of each wide node
+    l.rootOf = c.take(sizeof(uint32_t) * static_cast<size_t>(l.wideMax)); // binary root (or run) of each wide node
+    l.leafParent = c.take(sizeof(uint32_t) * static_cast<size_t>(compactedNum)); // of leaves with a run node
     // build scratch: (sorted position, leaf's parent) of every triangle record. The padded leaf boxes,
     // 24 B per leaf, borrow the triangle records' own space, which is written last.
     l.recSrc = c.take(sizeof(uint2) * static_cast<size_t>(faceNum));
@@ -189,16 +203,33 @@ struct CollapseLds {
     uint32_t ref[8][BT]; // binary node, or LEAF | leaf index
     uint32_t aux[8][BT]; // leaf: its parent binary node; subtree: half box area (float)
 };
-__device__ __forceinline__ void collapse_range(CollapseLds &lds, const kk_lbvh_device_data *__restrict__ lbvh,
-                                               const float *__restrict__ leafBoxes, Wide8 *__restrict__ out,
-                                               uint2 *__restrict__ recSrc, uint32_t *rootOf, BuildCtl *ctl,
-                                               uint32_t start, uint32_t end, uint32_t group, uint32_t groups) {
+struct CollapseArgs {
+    const kk_lbvh_device_data *lbvh;
+    const float *positions;  // the mesh, for the run nodes' chunk boxes
+    const uint32_t *tri;
+    const float *leafBoxes;
+    Wide8 *out;
+    uint2 *recSrc;
+    uint32_t *rootOf;
+    uint32_t *leafParent;
+    BuildCtl *ctl;
+};
+__device__ __forceinline__ void collapse_range(CollapseLds &lds, const CollapseArgs &args, uint32_t start,
+                                               uint32_t end, uint32_t group, uint32_t groups) {
+    const kk_lbvh_device_data *__restrict__ lbvh = args.lbvh;
+    const float *__restrict__ leafBoxes = args.leafBoxes;
+    Wide8 *__restrict__ out = args.out;
+    uint2 *__restrict__ recSrc = args.recSrc;
+    uint32_t *rootOf = args.rootOf;
+    uint32_t *leafParent = args.leafParent;
+    BuildCtl *ctl = args.ctl;
     auto &s_q = lds.q;
     auto &s_ref = lds.ref;
     auto &s_aux = lds.aux;
     const int tid = threadIdx.x, lane = tid & 63;
     const kk_lbvh_node *__restrict__ nodes = lbvh->internal_nodes;
     const uint32_t *__restrict__ compacted = lbvh->compacted_faces;
+    const uint32_t *__restrict__ faces = lbvh->faces;
     const uint32_t faceNum = lbvh->face_num, leafNum = lbvh->compacted_face_num;
 
     const float pad = leaf_pad(nodes);
@@ -207,28 +238,77 @@ __device__ __forceinline__ void collapse_range(CollapseLds &lds, const kk_lbvh_d
         k0 = compacted[l];
         k1 = (l == leafNum - 1) ? faceNum : compacted[l + 1];
     };
+    auto splits = [&](uint32_t leaf) { // does this leaf get a run node of its own?
+        uint32_t k0, k1;
+        runOf(leaf, k0, k1);
+        return k1 - k0 >= SPLIT_MIN && k1 - k0 <= SPLIT_MAX;
+    };
+    // quantisation frame of a node from its box grown by the pad
+    auto frame = [&](const f3 &lo, const f3 &hi, f3 &org, f3 &inv, f3 &extQ, int ex[3]) {
+        for (int a = 0; a < 3; ++a) {
+            org[a] = lo[a] - pad;
+            const float r = (hi[a] + pad - org[a]) / 253.f;
+            int e = r > 0.f ? ilogbf(r) + 1 : -100; // 2^e > extent / 253: offsets stay below 254
+            e = e < -100 ? -100 : (e > 100 ? 100 : e);
+            ex[a] = e;
+            inv[a] = ldexpf(1.f, -e);
+            extQ[a] = (hi[a] + pad - org[a]) * inv[a]; // the node's extent in byte units
+        }
+    };
+    // quantised outwards by one extra unit: the byte box contains the float box
+    auto quantise = [&](const AABB &b, const f3 &org, const f3 &inv) {
+        uint32_t lo[3], hi[3];
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = static_cast<uint32_t>(fminf(fmaxf(floorf((b.minPos[a] - org[a]) * inv[a]) - 1.f, 0.f), 255.f));
+            hi[a] = static_cast<uint32_t>(fmaxf(fminf(ceilf((b.maxPos[a] - org[a]) * inv[a]) + 1.f, 255.f), 0.f));
+        }
+        return make_uint2(lo[0] | (lo[1] << 8) | (lo[2] << 16) | (hi[0] << 24), hi[1] | (hi[2] << 8));
+    };
+    // slot = octant of the child's centre around the node's centre, nearest free one; 4 bits per slot:
+    // which of the cN children sits there (0xF: none)
+    auto assign_slots = [&](int cN, const f3 &extQ, const int ex[3]) {
+        uint32_t used = 0, childOf = 0xFFFFFFFFu;
+        for (int j = 0; j < cN; ++j) {
+            const uint2 q = s_q[j][tid];
+            // (centre of the slot - centre of the node) * 2, in world units
+            const float dx = ldexpf(static_cast<float>((q.x & 0xffu) + (q.x >> 24)) - extQ.x, ex[0]);
+            const float dy = ldexpf(static_cast<float>(((q.x >> 8) & 0xffu) + (q.y & 0xffu)) - extQ.y, ex[1]);
+            const float dz = ldexpf(static_cast<float>(((q.x >> 16) & 0xffu) + ((q.y >> 8) & 0xffu)) - extQ.z, ex[2]);
+            int bestS = 0;
+            float bestScore = -__builtin_inff();
+            for (int sl = 0; sl < 8; ++sl) {
+                if ((used >> sl) & 1u)
+                    continue;
+                const float score = ((sl & 1) ? dx : -dx) + ((sl & 2) ? dy : -dy) + ((sl & 4) ? dz : -dz);
+                if (!(score <= bestScore)) {
+                    bestScore = score;
+                    bestS = sl;
+                }
+            }
+            used |= 1u << bestS;
+            childOf = (childOf & ~(0xFu << (4 * bestS))) | (static_cast<uint32_t>(j) << (4 * bestS));
+        }
+        return childOf;
+    };
 
     for (uint32_t base = start + group * BT; base < end; base += groups * BT) {
         const uint32_t w = base + tid;
         const bool valid = w < end;
         int cN = 0;
-        uint32_t childOf = 0xFFFFFFFFu; // 4 bits per slot: which opened child sits there (0xF: none)
+        uint32_t childOf = 0xFFFFFFFFu;
         uint32_t imask = 0, leafMask = 0, ci = 0, ct = 0;
         f3 org = F3(0.f), inv = F3(0.f), extQ = F3(0.f);
         int ex[3] = {0, 0, 0};
-        if (valid) {
-            const uint32_t n = rootOf[w];
+        const uint32_t root = valid ? rootOf[w] : 0u;
+        const bool isRun = valid && (root & RUN_FLAG);
+        if (isRun) { // its chunks are made after the reservation; it asks for its triangles only
+            uint32_t k0, k1;
+            runOf(root & ~RUN_FLAG, k0, k1);
+            ct = k1 - k0;
+        } else if (valid) {
+            const uint32_t n = root;
             const trav::NodeData me = trav::load_node(nodes, n);
-            for (int a = 0; a < 3; ++a) {
-                org[a] = me.box.minPos[a] - pad;
-                const float r = (me.box.maxPos[a] + pad - org[a]) / 253.f;
-                int e = r > 0.f ? ilogbf(r) + 1 : -100; // 2^e > extent / 253: offsets stay below 254
-                e = e < -100 ? -100 : (e > 100 ? 100 : e);
-                ex[a] = e;
-                inv[a] = ldexpf(1.f, -e);
-                extQ[a] = (me.box.maxPos[a] + pad - org[a]) * inv[a]; // the node's extent in byte units
-            }
-            // quantised outwards by one extra unit: the byte box contains the float box
+            frame(me.box.minPos, me.box.maxPos, org, inv, extQ, ex);
             auto put = [&](int j, uint32_t c, uint32_t parent) {
                 AABB b;
                 uint32_t aux;
@@ -242,12 +322,7 @@ __device__ __forceinline__ void collapse_range(CollapseLds &lds, const kk_lbvh_d
                     const f3 e = b.maxPos - b.minPos;
                     aux = __float_as_uint(e.x * e.y + e.y * e.z + e.z * e.x);
                 }
-                uint32_t lo[3], hi[3];
-                for (int a = 0; a < 3; ++a) {
-                    lo[a] = static_cast<uint32_t>(fminf(fmaxf(floorf((b.minPos[a] - org[a]) * inv[a]) - 1.f, 0.f), 255.f));
-                    hi[a] = static_cast<uint32_t>(fmaxf(fminf(ceilf((b.maxPos[a] - org[a]) * inv[a]) + 1.f, 255.f), 0.f));
-                }
-                s_q[j][tid] = make_uint2(lo[0] | (lo[1] << 8) | (lo[2] << 16) | (hi[0] << 24), hi[1] | (hi[2] << 8));
+                s_q[j][tid] = quantise(b, org, inv);
                 s_ref[j][tid] = c;
                 s_aux[j][tid] = aux;
             };
@@ -276,34 +351,13 @@ __device__ __forceinline__ void collapse_range(CollapseLds &lds, const kk_lbvh_d
                 put(cN, ch.y, c);
                 ++cN;
             }
-            // slot = octant of the child's centre around the node's centre, nearest free one
-            uint32_t used = 0;
-            for (int j = 0; j < cN; ++j) {
-                const uint2 q = s_q[j][tid];
-                // (centre of the slot - centre of the node) * 2, in world units
-                const float dx = ldexpf(static_cast<float>((q.x & 0xffu) + (q.x >> 24)) - extQ.x, ex[0]);
-                const float dy = ldexpf(static_cast<float>(((q.x >> 8) & 0xffu) + (q.y & 0xffu)) - extQ.y, ex[1]);
-                const float dz = ldexpf(static_cast<float>(((q.x >> 16) & 0xffu) + ((q.y >> 8) & 0xffu)) - extQ.z, ex[2]);
-                int bestS = 0;
-                float bestScore = -__builtin_inff();
-                for (int sl = 0; sl < 8; ++sl) {
-                    if ((used >> sl) & 1u)
-                        continue;
-                    const float score = ((sl & 1) ? dx : -dx) + ((sl & 2) ? dy : -dy) + ((sl & 4) ? dz : -dz);
-                    if (!(score <= bestScore)) {
-                        bestScore = score;
-                        bestS = sl;
-                    }
-                }
-                used |= 1u << bestS;
-                childOf = (childOf & ~(0xFu << (4 * bestS))) | (static_cast<uint32_t>(j) << (4 * bestS));
-            }
+            childOf = assign_slots(cN, extQ, ex);
             for (int sl = 0; sl < 8; ++sl) {
                 const uint32_t j = (childOf >> (4 * sl)) & 0xFu;
                 if (j == 0xFu)
                     continue;
                 const uint32_t ref = s_ref[j][tid];
-                if (ref & LEAF) {
+                if ((ref & LEAF) && !splits(ref)) {
                     uint32_t k0, k1;
                     runOf(ref, k0, k1);
                     leafMask |= 1u << sl;
@@ -334,6 +388,62 @@ __device__ __forceinline__ void collapse_range(CollapseLds &lds, const kk_lbvh_d
         if (!valid)
             continue;
 
+        // a run node: its triangles in the order of their centres along the longest axis of those, cut
+        // into up to eight chunks of equal length, each with the box of its own triangles
+        uint8_t order[SPLIT_MAX];
+        uint32_t chunkAt[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        uint32_t runK0 = 0, runParent = 0;
+        if (isRun) {
+            const uint32_t leaf = root & ~RUN_FLAG;
+            uint32_t k1;
+            runOf(leaf, runK0, k1);
+            const uint32_t n = k1 - runK0;
+            runParent = leafParent[leaf];
+            const float *lb = leafBoxes + 6ull * leaf;
+            frame(F3(lb[0], lb[1], lb[2]), F3(lb[3], lb[4], lb[5]), org, inv, extQ, ex);
+            auto corner = [&](uint32_t i, int c) {
+                return trav::load_pos(args.positions, args.tri[3ull * faces[runK0 + i] + c]);
+            };
+            f3 cLo = F3(__builtin_inff()), cHi = F3(-__builtin_inff());
+            for (uint32_t i = 0; i < n; ++i) {
+                const f3 c = corner(i, 0) + corner(i, 1) + corner(i, 2);
+                for (int a = 0; a < 3; ++a) {
+                    cLo[a] = fminf(cLo[a], c[a]);
+                    cHi[a] = fmaxf(cHi[a], c[a]);
+                }
+            }
+            const f3 ce = cHi - cLo;
+            const int axis = ce.x >= ce.y ? (ce.x >= ce.z ? 0 : 2) : (ce.y >= ce.z ? 1 : 2);
+            float key[SPLIT_MAX];
+            for (uint32_t i = 0; i < n; ++i) { // insertion sort, stable; NaN keys stay where they are met
+                const float k = corner(i, 0)[axis] + corner(i, 1)[axis] + corner(i, 2)[axis];
+                uint32_t at = i;
+                while (at > 0 && key[at - 1] > k) {
+                    key[at] = key[at - 1];
+                    order[at] = order[at - 1];
+                    --at;
+                }
+                key[at] = k;
+                order[at] = static_cast<uint8_t>(i);
+            }
+            cN = n < 8u ? static_cast<int>(n) : 8;
+            const uint32_t each = n / cN, more = n % cN;
+            for (int j = 0; j < cN; ++j) {
+                chunkAt[j + 1] = chunkAt[j] + each + (static_cast<uint32_t>(j) < more ? 1u : 0u);
+                AABB b = AABB::Initial();
+                for (uint32_t i = chunkAt[j]; i < chunkAt[j + 1]; ++i)
+                    for (int c = 0; c < 3; ++c)
+                        b.Expand(corner(order[i], c));
+                b.minPos = b.minPos - pad;
+                b.maxPos = b.maxPos + pad;
+                s_q[j][tid] = quantise(b, org, inv);
+            }
+            childOf = assign_slots(cN, extQ, ex);
+            for (int sl = 0; sl < 8; ++sl)
+                if (((childOf >> (4 * sl)) & 0xFu) != 0xFu)
+                    leafMask |= 1u << sl;
+        }
+
         Wide8 rec;
         for (int a = 0; a < 3; ++a) {
             rec.origin[a] = org[a];
@@ -356,21 +466,36 @@ __device__ __forceinline__ void collapse_range(CollapseLds &lds, const kk_lbvh_d
             rec.q[0][sl] = static_cast<uint8_t>(q.x), rec.q[1][sl] = static_cast<uint8_t>(q.x >> 24);
             rec.q[2][sl] = static_cast<uint8_t>(q.x >> 8), rec.q[3][sl] = static_cast<uint8_t>(q.y);
             rec.q[4][sl] = static_cast<uint8_t>(q.x >> 16), rec.q[5][sl] = static_cast<uint8_t>(q.y >> 8);
-            const uint32_t ref = s_ref[j][tid];
-            if (!(ref & LEAF)) {
-                rootOf[childBase + rank] = ref;
-                ++rank;
-                continue;
+            uint32_t len;
+            if (isRun) {
+                len = chunkAt[j + 1] - chunkAt[j];
+                for (uint32_t i = chunkAt[j]; i < chunkAt[j + 1]; ++i)
+                    recSrc[triBase + run + (i - chunkAt[j])] = make_uint2(runK0 + order[i], runParent);
+            } else {
+                const uint32_t ref = s_ref[j][tid];
+                if (!(ref & LEAF)) {
+                    rootOf[childBase + rank] = ref;
+                    ++rank;
+                    continue;
+                }
+                if (splits(ref)) { // the slot keeps the leaf's box; its triangles hang one node further down
+                    rootOf[childBase + rank] = RUN_FLAG | (ref & LEAF_MASK);
+                    leafParent[ref & LEAF_MASK] = s_aux[j][tid];
+                    ++rank;
+                    continue;
+                }
+                uint32_t k0, k1;
+                runOf(ref, k0, k1);
+                len = k1 - k0;
+                const uint32_t parent = s_aux[j][tid];
+                for (uint32_t k = k0; k < k1; ++k)
+                    recSrc[triBase + run + (k - k0)] = make_uint2(k, parent);
             }
-            uint32_t k0, k1;
-            runOf(ref, k0, k1);
-            counts |= (k1 - k0 < 15u ? k1 - k0 : 15u) << (4 * sl);
-            longest = k1 - k0 > longest ? k1 - k0 : longest;
+            counts |= (len < 15u ? len : 15u) << (4 * sl);
+            longest = len > longest ? len : longest;
             rec.off16[sl] = static_cast<uint16_t>(run < 65535u ? run : 65535u);
-            rec.cnt16[sl] = static_cast<uint16_t>(k1 - k0 < 65535u ? k1 - k0 : 65535u);
-            const uint32_t parent = s_aux[j][tid];
-            for (uint32_t k = k0; k < k1; ++k, ++run)
-                recSrc[triBase + run] = make_uint2(k, parent);
+            rec.cnt16[sl] = static_cast<uint16_t>(len < 65535u ? len : 65535u);
+            run += len;
         }
         const bool huge = ct > 65535u;
         rec.leafMask = leafMask | (longest > 15u ? LONG_RUN : 0u) | (huge ? HUGE_RUN : 0u);
@@ -385,24 +510,19 @@ __device__ __forceinline__ void collapse_range(CollapseLds &lds, const kk_lbvh_d
     }
 }
 
-__global__ __launch_bounds__(BT) void collapse_level_kernel(
-    const kk_lbvh_device_data *__restrict__ lbvh, const float *__restrict__ leafBoxes,
-    Wide8 *__restrict__ out, uint2 *__restrict__ recSrc, uint32_t *__restrict__ rootOf, BuildCtl *ctl,
-    int level) {
+__global__ __launch_bounds__(BT) void collapse_level_kernel(CollapseArgs args, int level) {
     __shared__ CollapseLds lds;
-    const uint32_t start = ctl->bounds[level], end = ctl->bounds[level + 1];
+    const uint32_t start = args.ctl->bounds[level], end = args.ctl->bounds[level + 1];
     if (start >= end)
         return;
-    collapse_range(lds, lbvh, leafBoxes, out, recSrc, rootOf, ctl, start, end, blockIdx.x, gridDim.x);
+    collapse_range(lds, args, start, end, blockIdx.x, gridDim.x);
 }
 
 // Levels from `level` on, in one workgroup: past the first dozen levels a tree has few nodes left (or
 // none), and a launch per level would cost more than the work. What one level wrote is read by the
 // next after a device-scope fence and a barrier.
-__global__ __launch_bounds__(BT) void collapse_tail_kernel(
-    const kk_lbvh_device_data *__restrict__ lbvh, const float *__restrict__ leafBoxes,
-    Wide8 *__restrict__ out, uint2 *__restrict__ recSrc, uint32_t *rootOf, BuildCtl *ctl, Header *hdr,
-    int level) {
+__global__ __launch_bounds__(BT) void collapse_tail_kernel(CollapseArgs args, Header *hdr, int level) {
+    BuildCtl *ctl = args.ctl;
     __shared__ CollapseLds lds;
     __shared__ uint32_t s_range[2];
     for (; level < MAX_LEVELS; ++level) {
@@ -414,7 +534,7 @@ __global__ __launch_bounds__(BT) void collapse_tail_kernel(
         const uint32_t start = s_range[0], end = s_range[1];
         if (start >= end)
             return; // an empty level: nothing below it either
-        collapse_range(lds, lbvh, leafBoxes, out, recSrc, rootOf, ctl, start, end, 0u, 1u);
+        collapse_range(lds, args, start, end, 0u, 1u);
         __threadfence();
         __syncthreads();
         if (threadIdx.x == 0) { // what close_level_kernel does between launches
@@ -820,19 +940,21 @@ extern "C" int kk_trace_accel_build_with_leaf_boxes(const kk_lbvh_device_data *d
         KK_LAUNCH_CHECK();
         leafBoxes = own;
     }
-    uint32_t grid = div_up(nodeNum, BT);
+    const CollapseArgs args{d_lbvh, d_positions, d_face_pos_idx, leafBoxes, wide, recSrc, rootOf,
+                            reinterpret_cast<uint32_t *>(b + l.leafParent), ctl};
+    uint32_t grid = div_up(l.wideMax, BT);
     if (grid > 2048)
         grid = 2048;
     constexpr int TAIL_FROM = 12; // a launch per level up to here, one workgroup for the rest
     for (int level = 0; level < TAIL_FROM; ++level) {
         // level l has at most 8^l nodes
         const uint32_t g = level < 7 ? (grid < div_up(1u << (3 * level), BT) ? grid : div_up(1u << (3 * level), BT)) : grid;
-        collapse_level_kernel<<<g, BT, 0, stream>>>(d_lbvh, leafBoxes, wide, recSrc, rootOf, ctl, level);
+        collapse_level_kernel<<<g, BT, 0, stream>>>(args, level);
         KK_LAUNCH_CHECK();
         close_level_kernel<<<1, 1, 0, stream>>>(ctl, hdr, level);
         KK_LAUNCH_CHECK();
     }
-    collapse_tail_kernel<<<1, BT, 0, stream>>>(d_lbvh, leafBoxes, wide, recSrc, rootOf, ctl, hdr, TAIL_FROM);
+    collapse_tail_kernel<<<1, BT, 0, stream>>>(args, hdr, TAIL_FROM);
     KK_LAUNCH_CHECK();
     fill_records_kernel<<<div_up(face_num, THREADS), THREADS, 0, stream>>>(
         d_lbvh, d_positions, d_face_pos_idx, recSrc, reinterpret_cast<TriRec *>(b + l.tris));

@@ -310,6 +310,9 @@ struct Visit {
     uint32_t childBase;    // wide node of the first subtree slot
     uint32_t leafW, leafC; // triangle records from the first to the last hit leaf slot (leafC == 0: none)
     uint32_t leafSlots;    // all leaf slots of the record
+    uint32_t leafHits;     // the leaf slots that are hit
+    uint32_t counts;       // the record's count word (4 bits per slot unless LONG_RUN / HUGE_RUN)
+    uint32_t flags;        // the record's leaf word (leafSlots, LONG_RUN, HUGE_RUN)
 };
 
 // Slab tests of the eight slots of record `cur` against the ray, conservative: a slot is dropped only
@@ -373,6 +376,9 @@ __device__ __forceinline__ Visit visit_record(const char *__restrict__ wideBytes
     v.leafSlots = r1.z & 0xffu;
     v.leafW = v.leafC = 0u;
     const uint32_t leafHits = hits & r1.z & 0xffu;
+    v.leafHits = leafHits;
+    v.counts = r1.w;
+    v.flags = r1.z;
     if (leafHits != 0u) {
         if (r1.z & HUGE_RUN) {
             v.leafW = r1.y;

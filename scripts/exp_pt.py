@@ -25,6 +25,9 @@ if __name__ == "__main__":
                           "rays_per_path": round(v[4] / (1920 * 1080 * spp), 2),
                           "visits_per_ray": round(v[5] / max(v[4], 1), 2),
                           "tris_per_ray": round(v[6] / max(v[4], 1), 2),
+                          "tris_of_hit_slots_per_ray": round(v[14] / max(v[4], 1), 2),
+                          "tri_rounds_per_walk_pass": round(v[7] / max(v[0], 1), 2),
+                          "pairs_per_tri_round": round(v[15] / max(v[7], 1), 1),
                           "walk_passes_per_shade": round(v[0] / max(v[2], 1), 1),
                           "cycles_frac": {k: round(v[8 + i] / max(sum(v[8:15]), 1), 3) for i, k in
                                           enumerate(("walk_loop", "visit", "tri", "lights", "bounce", "end", "coop"))},

@@ -1,4 +1,4 @@
-"""profiles/r01_lbvh_build_pmc.json: per kernel of the LBVH build, the trace-side build and the VDB build,
+"""profiles/<tag>_build_pmc.json: per kernel of the LBVH build, the trace-side build and the VDB build,
 the bytes moved to and from memory (separate rocprofv3 --pmc passes, scripts/collect_profiles.sh) beside
 the kernel's average duration (kernel-trace stats of the same driver, scripts/prof_small.py)."""
 import csv
@@ -29,7 +29,7 @@ for g, prefixes in groups.items():
                      "read_MB": round(rd / 1e6, 1), "write_MB": round(wr / 1e6, 1),
                      "GBps": round((rd + wr) / (avg_us * 1e-6) / 1e9, 1) if avg_us else None})
     out[g] = sorted(rows, key=lambda r: -(r["avg_us"] or 0))
-json.dump(out, open("profiles/r01_build_pmc.json", "w"), indent=1)
+json.dump(out, open("profiles/%s_build_pmc.json" % __import__("os").environ.get("KK_PROFILE_TAG", "r02"), "w"), indent=1)
 for g in groups:
     print(g)
     for r in out[g]:

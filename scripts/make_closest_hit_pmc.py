@@ -1,4 +1,4 @@
-"""profiles/r01_closest_hit_pmc.json from a PMC summary (scripts/collect_profiles.sh): HBM-side bytes of the
+"""profiles/<tag>_closest_hit_pmc.json from a PMC summary (scripts/collect_profiles.sh): HBM-side bytes of the
 closest-hit kernel per launch, as bench.py reports them in roofline.traffic."""
 import json
 import sys
@@ -41,5 +41,5 @@ if "GRBM_GUI_ACTIVE" in c:
         "l1_to_l2_read_requests_per_launch": c["TCP_TCC_READ_REQ_sum"],
         "vector_load_wave_instructions_per_launch": c["TA_FLAT_READ_WAVEFRONTS_sum"],
     }
-json.dump(out, open("profiles/r01_closest_hit_pmc.json", "w"), indent=1)
+json.dump(out, open("profiles/%s_closest_hit_pmc.json" % __import__("os").environ.get("KK_PROFILE_TAG", "r02"), "w"), indent=1)
 print(json.dumps(out, indent=1))

@@ -43,6 +43,9 @@ def _read(bvh):
     return wide, tris, parents, nodes, N, M
 
 
+stats = {}
+
+
 def _check(bvh, pos, tri):
     wide, tris, parents, nodes, N, M = _read(bvh)
     W = len(wide)
@@ -77,6 +80,25 @@ def _check(bvh, pos, tri):
     np.add.at(tranges, (wide["triBase"] + tri_total)[tri_total > 0], -1)
     assert (np.cumsum(tranges)[:N] == 1).all()
     assert int(tri_total.sum()) == N
+    # a leaf of 4..120 triangles hangs under a node of its own, cut into chunks: a slot of that many
+    # triangles is found only in such a node, all of whose triangles belong to one leaf
+    compacted = bvh.d_compacted[:M].cpu().numpy().view(np.uint32)
+    leaf_of_rec = np.searchsorted(compacted, tris["k"], side="right") - 1
+    leaf_len = np.diff(np.append(compacted, np.uint32(N)).astype(np.int64))
+    first_leaf = leaf_of_rec[np.minimum(wide["triBase"], N - 1)]
+    last_leaf = leaf_of_rec[np.clip(wide["triBase"] + tri_total - 1, 0, N - 1)]
+    run_node = ((imask == 0) & (tri_total >= 4) & (tri_total <= 120) & (first_leaf == last_leaf) &
+                (leaf_len[first_leaf] == tri_total))
+    mid = ((cnt >= 4) & (cnt <= 120) & is_leaf).any(axis=1) & ~huge
+    assert run_node[mid].all()
+    for wn in np.nonzero(run_node)[0][:2000]:
+        leaves = leaf_of_rec[wide["triBase"][wn]:wide["triBase"][wn] + tri_total[wn]]
+        assert (leaves == leaves[0]).all()
+        assert np.count_nonzero(is_leaf[wn]) == min(8, tri_total[wn])
+        assert cnt[wn][is_leaf[wn]].max() - cnt[wn][is_leaf[wn]].min() <= 1
+    # ... and every leaf of that many triangles has one
+    assert int(run_node.sum()) == int(((leaf_len >= 4) & (leaf_len <= 120)).sum())
+    stats["run_nodes"] = int(run_node.sum())
     # vertices are the mesh's
     p = pos.reshape(-1, 3)
     t = tri.reshape(-1, 3)
@@ -131,6 +153,29 @@ def test_wide_tree_with_long_runs_and_tiny_meshes():
     bvh = LBVH(DEV)
     bvh.BuildFrom(pos, tri)
     _check(bvh, pos, tri)
+    # clusters of 1..60 triangles, each inside one Morton cell: leaves of every length up to 60
+    pos, tri = syn.triangle_soup(30_000, half_extent=0.02)
+    sizes = 1 + (np.arange(2000) * 7919) % 60
+    cluster = np.searchsorted(np.cumsum(sizes), np.arange(30_000), side="right") % 2000
+    centre = syn.triangle_soup(2000, seed=5)[0].reshape(-1, 3, 3)[:, 0]
+    pos = (pos.reshape(-1, 3, 3) * np.float32(1e-4) + centre[cluster][:, None, :]).astype(np.float32).reshape(-1, 3)
+    bvh = LBVH(DEV)
+    bvh.BuildFrom(pos, tri)
+    _check(bvh, pos, tri)
+    assert stats["run_nodes"] > 500
+    # one leaf of n triangles between two far triangles that span the scene
+    for n in (3, 4, 37, 120, 121):
+        p, t = syn.triangle_soup(n + 2, half_extent=0.02)
+        p = p.copy().reshape(-1, 3, 3)
+        p[:n] = p[:n] * np.float32(1e-5) + np.float32(0.5)
+        p[n] = p[n] * np.float32(1e-3)
+        p[n + 1] = p[n + 1] * np.float32(1e-3) + np.float32(1.0)
+        p = p.reshape(-1, 3).astype(np.float32)
+        b = LBVH(DEV)
+        b.BuildFrom(p, t)
+        _check(b, p, t)
+        assert b.GetDeviceData()["compactedFaceNum"] == 3
+        assert stats["run_nodes"] == (1 if 4 <= n <= 120 else 0)
     for n in (1, 2, 3, 9):
         p, t = syn.triangle_soup(n)
         b = LBVH(DEV)
