@@ -403,28 +403,6 @@ __device__ __forceinline__ bool final_hit_passes(const kk_lbvh_node *__restrict_
     return accel::passes_parent(nodes, b.w, ray);
 }
 
-// Inclusive prefix sum / running maximum over the 64 lanes of a wave with data-parallel-primitive moves:
-// four shifts inside each row of 16 lanes, then the last lane of a row into the rows after it.
-__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v) {
-    v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x111, 0xf, 0xf, false));
-    v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x112, 0xf, 0xf, false));
-    v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x114, 0xf, 0xf, false));
-    v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x118, 0xf, 0xf, false));
-    v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x142, 0xa, 0xf, false));
-    v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x143, 0xc, 0xf, false));
-    return v;
-}
-__device__ __forceinline__ uint32_t wave_inclusive_max(uint32_t v) {
-    auto mx = [](uint32_t a, int b) { return a > static_cast<uint32_t>(b) ? a : static_cast<uint32_t>(b); };
-    v = mx(v, __builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x111, 0xf, 0xf, false));
-    v = mx(v, __builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x112, 0xf, 0xf, false));
-    v = mx(v, __builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x114, 0xf, 0xf, false));
-    v = mx(v, __builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x118, 0xf, 0xf, false));
-    v = mx(v, __builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x142, 0xa, 0xf, false));
-    v = mx(v, __builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x143, 0xc, 0xf, false));
-    return v;
-}
-
 struct PathState {
     // the path
     uint32_t pixel;  // y * W + x
@@ -601,90 +579,18 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(KK_PT_W
             // up with what its own one-by-one loop would keep - the smallest (t, sorted position) among
             // its triangles that are hit, nearer than its best and accepted. One long leaf or a few
             // lanes with work do not hold the other lanes up for a pass per triangle.
-            while (true) {
-                const bool walking = stage == ST_WALK_C || stage == ST_WALK_S;
-                const uint32_t c = walking ? (pendC < 64u ? pendC : 64u) : 0u;
-                if (__ballot(c != 0u) == 0ull)
-                    break;
-                const uint32_t incl = wave_inclusive_sum(c);
-                const uint32_t start = incl - c;
-                const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
+            while (__ballot((stage == ST_WALK_C || stage == ST_WALK_S) && pendC != 0u) != 0ull) {
+                uint32_t tested = 0u, pairs = 0u;
+                const bool won = pooled_round<COUNT, false, false>(
+                    view.recs, nodes, view.parents, s_key + (tid & ~63), s_mark + (tid & ~63), lane, ray, mode,
+                    stage == ST_WALK_C, stage == ST_WALK_C || stage == ST_WALK_S, pendW, pendC, best, tested, pairs);
+                if (won && stage == ST_WALK_S)
+                    stage = ST_DONE_S_HIT;
                 if (COUNT) {
                     ++cntRounds;
-                    cntPairs += total < 64u ? total : 64u;
+                    cntPairs += pairs;
+                    cntTris += tested;
                 }
-                // owner of pair i = the last lane whose first pair is at or before i: every owner marks
-                // its first pair, a running maximum over the pairs spreads the marks
-                s_mark[tid] = 0u;
-                s_key[tid] = ~0ull;
-                __builtin_amdgcn_wave_barrier();
-                if (c != 0u && start < 64u)
-                    s_mark[(tid & ~63) + start] = static_cast<uint32_t>(lane);
-                __builtin_amdgcn_wave_barrier();
-                const bool pairOn = static_cast<uint32_t>(lane) < total;
-                const int own = static_cast<int>(wave_inclusive_max(s_mark[tid]));
-                auto fromF = [&](float v) { return __shfl(v, own, 64); };
-                auto fromU = [&](uint32_t v) { return static_cast<uint32_t>(__shfl(static_cast<int>(v), own, 64)); };
-                RayState oray;
-                oray.pos = F3(fromF(ray.pos.x), fromF(ray.pos.y), fromF(ray.pos.z));
-                oray.dir = F3(fromF(ray.dir.x), fromF(ray.dir.y), fromF(ray.dir.z));
-                const float oT = fromF(best.t);
-                const uint32_t oK = fromU(best.k);
-                const uint32_t rec = fromU(pendW - start) + static_cast<uint32_t>(lane);
-                const uint32_t oModeStage = fromU(mode | (stage << 8));
-                const uint32_t oMode = oModeStage & 0xffu;
-                const bool oClosest = (oModeStage >> 8) == ST_WALK_C;
-                unsigned long long key = ~0ull;
-                float t = 0.f, bx = 0.f, by = 0.f;
-                uint32_t fi = 0u;
-                if (pairOn) {
-                    const uint4 *tp = reinterpret_cast<const uint4 *>(view.recs + rec);
-                    const uint4 a = tp[0], b = tp[1], cc = tp[2];
-                    const f3 v0 = F3(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z));
-                    const f3 v1 = F3(__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z));
-                    const f3 v2 = F3(__uint_as_float(cc.x), __uint_as_float(cc.y), __uint_as_float(cc.z));
-                    t = HitTriangle(Ray{oray.pos, oray.dir}, v0, v1, v2, bx, by);
-                    fi = a.w;
-                    bool cand = t >= 0.f && (t < oT || (oClosest && t == oT && cc.w < oK));
-                    if (cand && oMode != MODE_FAST) {
-                        oray.inv = 1.f / oray.dir; // (a ray with a zero component is in MODE_CHAIN, which divides)
-                        cand = oMode == MODE_CAREFUL ? passes_parent(nodes, b.w, oray)
-                                                     : passes_chain(nodes, view.parents, b.w, oray);
-                    }
-                    if (cand) {
-                        // t >= 0: its bits order like the value ("+ 0" turns -0 into +0)
-                        key = (static_cast<unsigned long long>(__float_as_uint(t + 0.f)) << 32) | cc.w;
-                        atomicMin(&s_key[(tid & ~63) + own], key);
-                    }
-                }
-                const uint32_t served = (incl < 64u ? incl : 64u) - (start < 64u ? start : 64u);
-                if (COUNT)
-                    cntTris += served;
-                pendW += served;
-                pendC -= served;
-                if (__ballot(key != ~0ull) == 0ull)
-                    continue; // no pair of this round is a hit its owner would take
-                __builtin_amdgcn_wave_barrier();
-                // the owner's winning pair hands over its hit
-                const unsigned long long winners = __ballot(key != ~0ull && s_key[(tid & ~63) + own] == key);
-                const unsigned long long mine = served == 0u ? 0ull : ((served == 64u ? ~0ull : ((1ull << served) - 1ull)) << (start & 63u));
-                const int win = __ffsll(static_cast<long long>(winners & mine)) - 1;
-                const int src = win < 0 ? lane : win;
-                const float wt = __shfl(t, src, 64), wbx = __shfl(bx, src, 64), wby = __shfl(by, src, 64);
-                const uint32_t wfi = static_cast<uint32_t>(__shfl(static_cast<int>(fi), src, 64));
-                if (win >= 0) {
-                    if (stage == ST_WALK_S)
-                        stage = ST_DONE_S_HIT;
-                    else {
-                        best.t = wt;
-                        best.bx = wbx;
-                        best.by = wby;
-                        best.fi = wfi;
-                        best.k = static_cast<uint32_t>(s_key[tid]);
-                        best.w = pendW - served + (static_cast<uint32_t>(win) - start);
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();
             }
             lap(tcT);
         }
