@@ -540,20 +540,9 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(KK_PT_W
             if (stage == ST_WALK_C || stage == ST_WALK_S) {
                 if (pendC == 0u) {
                     uint32_t cur;
-                    if (!w.next(st, deep, sg.oct, cur)) {
-                        if (stage == ST_WALK_S)
-                            stage = ST_DONE_S_CLEAR;
-                        else if (best.fi != 0xFFFFFFFFu && mode == MODE_FAST &&
-                                 !final_hit_passes(nodes, view.recs, best.w, ray)) {
-                            // the final hit fails its parent-box test: walk again, checking every hit
-                            mode = MODE_CAREFUL;
-                            best.t = FloatMax;
-                            best.bx = best.by = 0.f;
-                            best.fi = best.k = best.w = 0xFFFFFFFFu;
-                            w.start(sg.oct);
-                        } else
-                            stage = ST_DONE_C;
-                    } else {
+                    if (!w.next(st, deep, sg.oct, cur))
+                        stage = stage == ST_WALK_S ? ST_DONE_S_CLEAR : ST_DONE_C;
+                    else {
                         const float limit = best.t + trav::CULL_SLACK * best.t;
                         bool unusedFlag = false;
                         const Visit vis = visit_record<false>(wideBytes, cur, ray, sg, limit, unusedFlag);
@@ -599,6 +588,19 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(KK_PT_W
             break;
 
         // ================= shade: every lane takes its path to its next ray =============================
+        // A closest-hit walk in the fast mode took its hits unchecked: the final one must pass the test of
+        // its leaf's parent box, else the lane walks the ray again, checking every hit as it meets it
+        // (and consumes nothing this time round).
+        if (stage == ST_DONE_C && best.fi != 0xFFFFFFFFu && mode == MODE_FAST &&
+            !final_hit_passes(nodes, view.recs, best.w, ray)) {
+            mode = MODE_CAREFUL;
+            best.t = FloatMax;
+            best.bx = best.by = 0.f;
+            best.fi = best.k = best.w = 0xFFFFFFFFu;
+            pendC = 0u;
+            w.start(sg.oct);
+            stage = ST_WALK_C;
+        }
         consume_walk();
         // light samples until the lane has a shadow ray out or is through its lights (:353-380)
         while (true) {
