@@ -203,6 +203,77 @@ struct CollapseLds {
     uint32_t ref[8][BT]; // binary node, or LEAF | leaf index
     uint32_t aux[8][BT]; // leaf: its parent binary node; subtree: half box area (float)
 };
+// Quantisation frame of a wide node: its box grown by the pad, 2^ex per byte unit and axis.
+struct QFrame {
+    f3 org, inv, extQ; // origin, 2^-ex, the node's extent in byte units
+    int ex[3];
+};
+__device__ __forceinline__ QFrame make_frame(const f3 &lo, const f3 &hi, float pad) {
+    QFrame f;
+    for (int a = 0; a < 3; ++a) {
+        f.org[a] = lo[a] - pad;
+        const float r = (hi[a] + pad - f.org[a]) / 253.f;
+        int e = r > 0.f ? ilogbf(r) + 1 : -100; // 2^e > extent / 253: offsets stay below 254
+        e = e < -100 ? -100 : (e > 100 ? 100 : e);
+        f.ex[a] = e;
+        f.inv[a] = ldexpf(1.f, -e);
+        f.extQ[a] = (hi[a] + pad - f.org[a]) * f.inv[a];
+    }
+    return f;
+}
+// quantised outwards by one extra unit: the byte box contains the float box.
+// x: minx miny minz maxx (bytes), y: maxy maxz
+__device__ __forceinline__ uint2 quantise_box(const AABB &b, const QFrame &f) {
+    uint32_t lo[3], hi[3];
+    for (int a = 0; a < 3; ++a) {
+        lo[a] = static_cast<uint32_t>(fminf(fmaxf(floorf((b.minPos[a] - f.org[a]) * f.inv[a]) - 1.f, 0.f), 255.f));
+        hi[a] = static_cast<uint32_t>(fmaxf(fminf(ceilf((b.maxPos[a] - f.org[a]) * f.inv[a]) + 1.f, 255.f), 0.f));
+    }
+    return make_uint2(lo[0] | (lo[1] << 8) | (lo[2] << 16) | (hi[0] << 24), hi[1] | (hi[2] << 8));
+}
+// slot = octant of the child's centre around the node's centre, nearest free one; 4 bits per slot of the
+// result: which of the cN children (byte boxes q[j * stride]) sits there (0xF: none)
+__device__ __forceinline__ uint32_t assign_slots(int cN, const QFrame &f, const uint2 *q, int stride) {
+    uint32_t used = 0, childOf = 0xFFFFFFFFu;
+    for (int j = 0; j < cN; ++j) {
+        const uint2 b = q[j * stride];
+        // (centre of the slot - centre of the node) * 2, in world units
+        const float dx = ldexpf(static_cast<float>((b.x & 0xffu) + (b.x >> 24)) - f.extQ.x, f.ex[0]);
+        const float dy = ldexpf(static_cast<float>(((b.x >> 8) & 0xffu) + (b.y & 0xffu)) - f.extQ.y, f.ex[1]);
+        const float dz = ldexpf(static_cast<float>(((b.x >> 16) & 0xffu) + ((b.y >> 8) & 0xffu)) - f.extQ.z, f.ex[2]);
+        int bestS = 0;
+        float bestScore = -__builtin_inff();
+        for (int sl = 0; sl < 8; ++sl) {
+            if ((used >> sl) & 1u)
+                continue;
+            const float score = ((sl & 1) ? dx : -dx) + ((sl & 2) ? dy : -dy) + ((sl & 4) ? dz : -dz);
+            if (!(score <= bestScore)) {
+                bestScore = score;
+                bestS = sl;
+            }
+        }
+        used |= 1u << bestS;
+        childOf = (childOf & ~(0xFu << (4 * bestS))) | (static_cast<uint32_t>(j) << (4 * bestS));
+    }
+    return childOf;
+}
+__device__ __forceinline__ void set_slot_box(Wide8 &rec, int sl, uint2 q) {
+    rec.q[0][sl] = static_cast<uint8_t>(q.x), rec.q[1][sl] = static_cast<uint8_t>(q.x >> 24);
+    rec.q[2][sl] = static_cast<uint8_t>(q.x >> 8), rec.q[3][sl] = static_cast<uint8_t>(q.y);
+    rec.q[4][sl] = static_cast<uint8_t>(q.x >> 16), rec.q[5][sl] = static_cast<uint8_t>(q.y >> 8);
+}
+__device__ __forceinline__ void set_slot_empty(Wide8 &rec, int sl) { // cannot be hit
+    rec.q[0][sl] = rec.q[2][sl] = rec.q[4][sl] = 255;
+    rec.q[1][sl] = rec.q[3][sl] = rec.q[5][sl] = 0;
+}
+__device__ __forceinline__ void store_record(Wide8 *out, const Wide8 &rec) {
+    uint4 *o = reinterpret_cast<uint4 *>(out);
+    const uint4 *src = reinterpret_cast<const uint4 *>(&rec);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        o[i] = src[i];
+}
+
 struct CollapseArgs {
     const kk_lbvh_device_data *lbvh;
     const float *positions;  // the mesh, for the run nodes' chunk boxes
@@ -229,7 +300,6 @@ __device__ __forceinline__ void collapse_range(CollapseLds &lds, const CollapseA
     const int tid = threadIdx.x, lane = tid & 63;
     const kk_lbvh_node *__restrict__ nodes = lbvh->internal_nodes;
     const uint32_t *__restrict__ compacted = lbvh->compacted_faces;
-    const uint32_t *__restrict__ faces = lbvh->faces;
     const uint32_t faceNum = lbvh->face_num, leafNum = lbvh->compacted_face_num;
 
     const float pad = leaf_pad(nodes);
@@ -238,77 +308,25 @@ __device__ __forceinline__ void collapse_range(CollapseLds &lds, const CollapseA
         k0 = compacted[l];
         k1 = (l == leafNum - 1) ? faceNum : compacted[l + 1];
     };
-    auto splits = [&](uint32_t leaf) { // does this leaf get a run node of its own?
-        uint32_t k0, k1;
-        runOf(leaf, k0, k1);
-        return k1 - k0 >= SPLIT_MIN && k1 - k0 <= SPLIT_MAX;
-    };
-    // quantisation frame of a node from its box grown by the pad
-    auto frame = [&](const f3 &lo, const f3 &hi, f3 &org, f3 &inv, f3 &extQ, int ex[3]) {
-        for (int a = 0; a < 3; ++a) {
-            org[a] = lo[a] - pad;
-            const float r = (hi[a] + pad - org[a]) / 253.f;
-            int e = r > 0.f ? ilogbf(r) + 1 : -100; // 2^e > extent / 253: offsets stay below 254
-            e = e < -100 ? -100 : (e > 100 ? 100 : e);
-            ex[a] = e;
-            inv[a] = ldexpf(1.f, -e);
-            extQ[a] = (hi[a] + pad - org[a]) * inv[a]; // the node's extent in byte units
-        }
-    };
-    // quantised outwards by one extra unit: the byte box contains the float box
-    auto quantise = [&](const AABB &b, const f3 &org, const f3 &inv) {
-        uint32_t lo[3], hi[3];
-        for (int a = 0; a < 3; ++a) {
-            lo[a] = static_cast<uint32_t>(fminf(fmaxf(floorf((b.minPos[a] - org[a]) * inv[a]) - 1.f, 0.f), 255.f));
-            hi[a] = static_cast<uint32_t>(fmaxf(fminf(ceilf((b.maxPos[a] - org[a]) * inv[a]) + 1.f, 255.f), 0.f));
-        }
-        return make_uint2(lo[0] | (lo[1] << 8) | (lo[2] << 16) | (hi[0] << 24), hi[1] | (hi[2] << 8));
-    };
-    // slot = octant of the child's centre around the node's centre, nearest free one; 4 bits per slot:
-    // which of the cN children sits there (0xF: none)
-    auto assign_slots = [&](int cN, const f3 &extQ, const int ex[3]) {
-        uint32_t used = 0, childOf = 0xFFFFFFFFu;
-        for (int j = 0; j < cN; ++j) {
-            const uint2 q = s_q[j][tid];
-            // (centre of the slot - centre of the node) * 2, in world units
-            const float dx = ldexpf(static_cast<float>((q.x & 0xffu) + (q.x >> 24)) - extQ.x, ex[0]);
-            const float dy = ldexpf(static_cast<float>(((q.x >> 8) & 0xffu) + (q.y & 0xffu)) - extQ.y, ex[1]);
-            const float dz = ldexpf(static_cast<float>(((q.x >> 16) & 0xffu) + ((q.y >> 8) & 0xffu)) - extQ.z, ex[2]);
-            int bestS = 0;
-            float bestScore = -__builtin_inff();
-            for (int sl = 0; sl < 8; ++sl) {
-                if ((used >> sl) & 1u)
-                    continue;
-                const float score = ((sl & 1) ? dx : -dx) + ((sl & 2) ? dy : -dy) + ((sl & 4) ? dz : -dz);
-                if (!(score <= bestScore)) {
-                    bestScore = score;
-                    bestS = sl;
-                }
-            }
-            used |= 1u << bestS;
-            childOf = (childOf & ~(0xFu << (4 * bestS))) | (static_cast<uint32_t>(j) << (4 * bestS));
-        }
-        return childOf;
-    };
-
+    auto splits = [](uint32_t len) { return len >= SPLIT_MIN && len <= SPLIT_MAX; }; // a run node of its own?
     for (uint32_t base = start + group * BT; base < end; base += groups * BT) {
         const uint32_t w = base + tid;
         const bool valid = w < end;
         int cN = 0;
         uint32_t childOf = 0xFFFFFFFFu;
         uint32_t imask = 0, leafMask = 0, ci = 0, ct = 0;
-        f3 org = F3(0.f), inv = F3(0.f), extQ = F3(0.f);
-        int ex[3] = {0, 0, 0};
+        QFrame fr{};
+        uint32_t lens[8]; // triangles of the leaf in a slot
         const uint32_t root = valid ? rootOf[w] : 0u;
         const bool isRun = valid && (root & RUN_FLAG);
-        if (isRun) { // its chunks are made after the reservation; it asks for its triangles only
+        if (isRun) { // made by run_nodes_kernel after the last level; here it reserves its triangles
             uint32_t k0, k1;
             runOf(root & ~RUN_FLAG, k0, k1);
             ct = k1 - k0;
         } else if (valid) {
             const uint32_t n = root;
             const trav::NodeData me = trav::load_node(nodes, n);
-            frame(me.box.minPos, me.box.maxPos, org, inv, extQ, ex);
+            fr = make_frame(me.box.minPos, me.box.maxPos, pad);
             auto put = [&](int j, uint32_t c, uint32_t parent) {
                 AABB b;
                 uint32_t aux;
@@ -322,7 +340,7 @@ __device__ __forceinline__ void collapse_range(CollapseLds &lds, const CollapseA
                     const f3 e = b.maxPos - b.minPos;
                     aux = __float_as_uint(e.x * e.y + e.y * e.z + e.z * e.x);
                 }
-                s_q[j][tid] = quantise(b, org, inv);
+                s_q[j][tid] = quantise_box(b, fr);
                 s_ref[j][tid] = c;
                 s_aux[j][tid] = aux;
             };
@@ -351,17 +369,22 @@ __device__ __forceinline__ void collapse_range(CollapseLds &lds, const CollapseA
                 put(cN, ch.y, c);
                 ++cN;
             }
-            childOf = assign_slots(cN, extQ, ex);
+            childOf = assign_slots(cN, fr, &s_q[0][tid], BT);
+#pragma unroll
             for (int sl = 0; sl < 8; ++sl) {
+                lens[sl] = 0u;
                 const uint32_t j = (childOf >> (4 * sl)) & 0xFu;
                 if (j == 0xFu)
                     continue;
                 const uint32_t ref = s_ref[j][tid];
-                if ((ref & LEAF) && !splits(ref)) {
+                if (ref & LEAF) {
                     uint32_t k0, k1;
                     runOf(ref, k0, k1);
+                    lens[sl] = k1 - k0;
+                }
+                if ((ref & LEAF) && !splits(lens[sl])) {
                     leafMask |= 1u << sl;
-                    ct += k1 - k0;
+                    ct += lens[sl];
                 } else
                     imask |= 1u << sl;
             }
@@ -388,109 +411,47 @@ __device__ __forceinline__ void collapse_range(CollapseLds &lds, const CollapseA
         if (!valid)
             continue;
 
-        // a run node: its triangles in the order of their centres along the longest axis of those, cut
-        // into up to eight chunks of equal length, each with the box of its own triangles
-        uint8_t order[SPLIT_MAX];
-        uint32_t chunkAt[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-        uint32_t runK0 = 0, runParent = 0;
         if (isRun) {
-            const uint32_t leaf = root & ~RUN_FLAG;
-            uint32_t k1;
-            runOf(leaf, runK0, k1);
-            const uint32_t n = k1 - runK0;
-            runParent = leafParent[leaf];
-            const float *lb = leafBoxes + 6ull * leaf;
-            frame(F3(lb[0], lb[1], lb[2]), F3(lb[3], lb[4], lb[5]), org, inv, extQ, ex);
-            auto corner = [&](uint32_t i, int c) {
-                return trav::load_pos(args.positions, args.tri[3ull * faces[runK0 + i] + c]);
-            };
-            f3 cLo = F3(__builtin_inff()), cHi = F3(-__builtin_inff());
-            for (uint32_t i = 0; i < n; ++i) {
-                const f3 c = corner(i, 0) + corner(i, 1) + corner(i, 2);
-                for (int a = 0; a < 3; ++a) {
-                    cLo[a] = fminf(cLo[a], c[a]);
-                    cHi[a] = fmaxf(cHi[a], c[a]);
-                }
-            }
-            const f3 ce = cHi - cLo;
-            const int axis = ce.x >= ce.y ? (ce.x >= ce.z ? 0 : 2) : (ce.y >= ce.z ? 1 : 2);
-            float key[SPLIT_MAX];
-            for (uint32_t i = 0; i < n; ++i) { // insertion sort, stable; NaN keys stay where they are met
-                const float k = corner(i, 0)[axis] + corner(i, 1)[axis] + corner(i, 2)[axis];
-                uint32_t at = i;
-                while (at > 0 && key[at - 1] > k) {
-                    key[at] = key[at - 1];
-                    order[at] = order[at - 1];
-                    --at;
-                }
-                key[at] = k;
-                order[at] = static_cast<uint8_t>(i);
-            }
-            cN = n < 8u ? static_cast<int>(n) : 8;
-            const uint32_t each = n / cN, more = n % cN;
-            for (int j = 0; j < cN; ++j) {
-                chunkAt[j + 1] = chunkAt[j] + each + (static_cast<uint32_t>(j) < more ? 1u : 0u);
-                AABB b = AABB::Initial();
-                for (uint32_t i = chunkAt[j]; i < chunkAt[j + 1]; ++i)
-                    for (int c = 0; c < 3; ++c)
-                        b.Expand(corner(order[i], c));
-                b.minPos = b.minPos - pad;
-                b.maxPos = b.maxPos + pad;
-                s_q[j][tid] = quantise(b, org, inv);
-            }
-            childOf = assign_slots(cN, extQ, ex);
-            for (int sl = 0; sl < 8; ++sl)
-                if (((childOf >> (4 * sl)) & 0xFu) != 0xFu)
-                    leafMask |= 1u << sl;
+            out[w].triBase = triBase;
+            continue;
         }
 
         Wide8 rec;
         for (int a = 0; a < 3; ++a) {
-            rec.origin[a] = org[a];
-            rec.exp[a] = static_cast<int8_t>(ex[a]);
+            rec.origin[a] = fr.org[a];
+            rec.exp[a] = static_cast<int8_t>(fr.ex[a]);
         }
         rec.imask = static_cast<uint8_t>(imask);
         rec.childBase = childBase;
         rec.triBase = triBase;
         uint32_t counts = 0, longest = 0;
         uint32_t rank = 0, run = 0;
+#pragma unroll
         for (int sl = 0; sl < 8; ++sl) {
             rec.off16[sl] = rec.cnt16[sl] = 0;
             const uint32_t j = (childOf >> (4 * sl)) & 0xFu;
-            if (j == 0xFu) { // an empty slot cannot be hit
-                rec.q[0][sl] = rec.q[2][sl] = rec.q[4][sl] = 255;
-                rec.q[1][sl] = rec.q[3][sl] = rec.q[5][sl] = 0;
+            if (j == 0xFu) {
+                set_slot_empty(rec, sl);
                 continue;
             }
-            const uint2 q = s_q[j][tid];
-            rec.q[0][sl] = static_cast<uint8_t>(q.x), rec.q[1][sl] = static_cast<uint8_t>(q.x >> 24);
-            rec.q[2][sl] = static_cast<uint8_t>(q.x >> 8), rec.q[3][sl] = static_cast<uint8_t>(q.y);
-            rec.q[4][sl] = static_cast<uint8_t>(q.x >> 16), rec.q[5][sl] = static_cast<uint8_t>(q.y >> 8);
-            uint32_t len;
-            if (isRun) {
-                len = chunkAt[j + 1] - chunkAt[j];
-                for (uint32_t i = chunkAt[j]; i < chunkAt[j + 1]; ++i)
-                    recSrc[triBase + run + (i - chunkAt[j])] = make_uint2(runK0 + order[i], runParent);
-            } else {
-                const uint32_t ref = s_ref[j][tid];
-                if (!(ref & LEAF)) {
-                    rootOf[childBase + rank] = ref;
-                    ++rank;
-                    continue;
-                }
-                if (splits(ref)) { // the slot keeps the leaf's box; its triangles hang one node further down
-                    rootOf[childBase + rank] = RUN_FLAG | (ref & LEAF_MASK);
-                    leafParent[ref & LEAF_MASK] = s_aux[j][tid];
-                    ++rank;
-                    continue;
-                }
-                uint32_t k0, k1;
-                runOf(ref, k0, k1);
-                len = k1 - k0;
-                const uint32_t parent = s_aux[j][tid];
-                for (uint32_t k = k0; k < k1; ++k)
-                    recSrc[triBase + run + (k - k0)] = make_uint2(k, parent);
+            set_slot_box(rec, sl, s_q[j][tid]);
+            const uint32_t ref = s_ref[j][tid];
+            if (!(ref & LEAF)) {
+                rootOf[childBase + rank] = ref;
+                ++rank;
+                continue;
             }
+            const uint32_t len = lens[sl];
+            if (splits(len)) { // the slot keeps the leaf's box; its triangles hang one node further down
+                rootOf[childBase + rank] = RUN_FLAG | (ref & LEAF_MASK);
+                leafParent[ref & LEAF_MASK] = s_aux[j][tid];
+                ++rank;
+                continue;
+            }
+            const uint32_t k0 = compacted[ref & LEAF_MASK];
+            const uint32_t parent = s_aux[j][tid];
+            for (uint32_t k = k0; k < k0 + len; ++k)
+                recSrc[triBase + run + (k - k0)] = make_uint2(k, parent);
             counts |= (len < 15u ? len : 15u) << (4 * sl);
             longest = len > longest ? len : longest;
             rec.off16[sl] = static_cast<uint16_t>(run < 65535u ? run : 65535u);
@@ -502,12 +463,105 @@ __device__ __forceinline__ void collapse_range(CollapseLds &lds, const CollapseA
         rec.counts = huge ? ct : counts;
         for (int i = 0; i < 4; ++i)
             rec.spare[i] = 0;
-        uint4 *o = reinterpret_cast<uint4 *>(out + w);
-        const uint4 *src = reinterpret_cast<const uint4 *>(&rec);
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-            o[i] = src[i];
+        store_record(out + w, rec);
     }
+}
+
+// The run nodes, after the last level (a thread per wide node; the few that are run nodes work): the
+// leaf's triangles in the order of their centres along the longest axis of those, cut into up to eight
+// chunks of equal length, each with the box of its own triangles.
+__global__ __launch_bounds__(BT) void run_nodes_kernel(CollapseArgs args, const Header *__restrict__ hdr) {
+    __shared__ uint2 s_q[8][BT];
+    const int tid = threadIdx.x;
+    const uint32_t w = blockIdx.x * BT + tid;
+    if (w >= hdr->wideNum)
+        return;
+    const uint32_t root = args.rootOf[w];
+    if (!(root & RUN_FLAG))
+        return;
+    const kk_lbvh_device_data *__restrict__ lbvh = args.lbvh;
+    const uint32_t *__restrict__ faces = lbvh->faces;
+    const uint32_t leaf = root & ~RUN_FLAG, leafNum = lbvh->compacted_face_num;
+    const uint32_t k0 = lbvh->compacted_faces[leaf];
+    const uint32_t k1 = leaf == leafNum - 1 ? lbvh->face_num : lbvh->compacted_faces[leaf + 1];
+    const uint32_t n = k1 - k0; // SPLIT_MIN .. SPLIT_MAX
+    const uint32_t parent = args.leafParent[leaf];
+    const uint32_t triBase = args.out[w].triBase;
+    const float pad = leaf_pad(lbvh->internal_nodes);
+    const float *lb = args.leafBoxes + 6ull * leaf;
+    const QFrame fr = make_frame(F3(lb[0], lb[1], lb[2]), F3(lb[3], lb[4], lb[5]), pad);
+    auto corner = [&](uint32_t i, int c) {
+        return trav::load_pos(args.positions, args.tri[3ull * faces[k0 + i] + c]);
+    };
+    f3 cLo = F3(__builtin_inff()), cHi = F3(-__builtin_inff());
+    for (uint32_t i = 0; i < n; ++i) {
+        const f3 c = corner(i, 0) + corner(i, 1) + corner(i, 2);
+        for (int a = 0; a < 3; ++a) {
+            cLo[a] = fminf(cLo[a], c[a]);
+            cHi[a] = fmaxf(cHi[a], c[a]);
+        }
+    }
+    const f3 ce = cHi - cLo;
+    const int axis = ce.x >= ce.y ? (ce.x >= ce.z ? 0 : 2) : (ce.y >= ce.z ? 1 : 2);
+    float key[SPLIT_MAX];
+    uint8_t order[SPLIT_MAX];
+    for (uint32_t i = 0; i < n && i < SPLIT_MAX; ++i) { // insertion sort, stable; NaN keys stay where they are met
+        const float k = corner(i, 0)[axis] + corner(i, 1)[axis] + corner(i, 2)[axis];
+        uint32_t at = i;
+        while (at > 0 && key[at - 1] > k) {
+            key[at] = key[at - 1];
+            order[at] = order[at - 1];
+            --at;
+        }
+        key[at] = k;
+        order[at] = static_cast<uint8_t>(i);
+    }
+    const int cN = n < 8u ? static_cast<int>(n) : 8;
+    const uint32_t each = n / cN, more = n % cN;
+    uint32_t chunkAt[9];
+    chunkAt[0] = 0;
+    for (int j = 0; j < cN; ++j) {
+        chunkAt[j + 1] = chunkAt[j] + each + (static_cast<uint32_t>(j) < more ? 1u : 0u);
+        AABB b = AABB::Initial();
+        for (uint32_t i = chunkAt[j]; i < chunkAt[j + 1]; ++i)
+            for (int c = 0; c < 3; ++c)
+                b.Expand(corner(order[i], c));
+        b.minPos = b.minPos - pad;
+        b.maxPos = b.maxPos + pad;
+        s_q[j][tid] = quantise_box(b, fr);
+    }
+    const uint32_t childOf = assign_slots(cN, fr, &s_q[0][tid], BT);
+    Wide8 rec;
+    for (int a = 0; a < 3; ++a) {
+        rec.origin[a] = fr.org[a];
+        rec.exp[a] = static_cast<int8_t>(fr.ex[a]);
+    }
+    rec.imask = 0;
+    rec.childBase = 0;
+    rec.triBase = triBase;
+    uint32_t counts = 0, leafMask = 0, run = 0;
+    for (int sl = 0; sl < 8; ++sl) {
+        rec.off16[sl] = rec.cnt16[sl] = 0;
+        const uint32_t j = (childOf >> (4 * sl)) & 0xFu;
+        if (j == 0xFu) {
+            set_slot_empty(rec, sl);
+            continue;
+        }
+        set_slot_box(rec, sl, s_q[j][tid]);
+        const uint32_t len = chunkAt[j + 1] - chunkAt[j]; // <= 15
+        for (uint32_t i = chunkAt[j]; i < chunkAt[j + 1]; ++i)
+            args.recSrc[triBase + run + (i - chunkAt[j])] = make_uint2(k0 + order[i], parent);
+        leafMask |= 1u << sl;
+        counts |= len << (4 * sl);
+        rec.off16[sl] = static_cast<uint16_t>(run);
+        rec.cnt16[sl] = static_cast<uint16_t>(len);
+        run += len;
+    }
+    rec.leafMask = leafMask;
+    rec.counts = counts;
+    for (int i = 0; i < 4; ++i)
+        rec.spare[i] = 0;
+    store_record(args.out + w, rec);
 }
 
 __global__ __launch_bounds__(BT) void collapse_level_kernel(CollapseArgs args, int level) {
@@ -956,6 +1010,10 @@ extern "C" int kk_trace_accel_build_with_leaf_boxes(const kk_lbvh_device_data *d
     }
     collapse_tail_kernel<<<1, BT, 0, stream>>>(args, hdr, TAIL_FROM);
     KK_LAUNCH_CHECK();
+    if (face_num - compacted_face_num >= SPLIT_MIN - 1) { // else no leaf is long enough for a run node
+        run_nodes_kernel<<<div_up(l.wideMax, BT), BT, 0, stream>>>(args, hdr);
+        KK_LAUNCH_CHECK();
+    }
     fill_records_kernel<<<div_up(face_num, THREADS), THREADS, 0, stream>>>(
         d_lbvh, d_positions, d_face_pos_idx, recSrc, reinterpret_cast<TriRec *>(b + l.tris));
     KK_LAUNCH_CHECK();

@@ -39,7 +39,7 @@ if "GRBM_GUI_ACTIVE" in c:
         "td_busy_frac": c["TD_TD_BUSY_sum"] / 256 / cycles,
         "l1_line_accesses_per_launch": c["TCP_TOTAL_CACHE_ACCESSES_sum"],
         "l1_to_l2_read_requests_per_launch": c["TCP_TCC_READ_REQ_sum"],
-        "vector_load_wave_instructions_per_launch": c["TA_FLAT_READ_WAVEFRONTS_sum"],
+        "vector_load_wave_instructions_per_launch": c.get("TA_FLAT_READ_WAVEFRONTS_sum", c.get("SQ_INSTS_VMEM_RD")),
     }
 json.dump(out, open("profiles/%s_closest_hit_pmc.json" % __import__("os").environ.get("KK_PROFILE_TAG", "r02"), "w"), indent=1)
 print(json.dumps(out, indent=1))
