@@ -202,6 +202,7 @@ struct CollapseLds {
     uint2 q[8][BT];      // x: minx miny minz maxx (bytes), y: maxy maxz
     uint32_t ref[8][BT]; // binary node, or LEAF | leaf index
     uint32_t aux[8][BT]; // leaf: its parent binary node; subtree: half box area (float)
+    uint32_t len[8][BT]; // leaf: its triangles
 };
 // Quantisation frame of a wide node: its box grown by the pad, 2^ex per byte unit and axis.
 struct QFrame {
@@ -316,7 +317,6 @@ __device__ __forceinline__ void collapse_range(CollapseLds &lds, const CollapseA
         uint32_t childOf = 0xFFFFFFFFu;
         uint32_t imask = 0, leafMask = 0, ci = 0, ct = 0;
         QFrame fr{};
-        uint32_t lens[8]; // triangles of the leaf in a slot
         const uint32_t root = valid ? rootOf[w] : 0u;
         const bool isRun = valid && (root & RUN_FLAG);
         if (isRun) { // made by run_nodes_kernel after the last level; here it reserves its triangles
@@ -370,21 +370,21 @@ __device__ __forceinline__ void collapse_range(CollapseLds &lds, const CollapseA
                 ++cN;
             }
             childOf = assign_slots(cN, fr, &s_q[0][tid], BT);
-#pragma unroll
             for (int sl = 0; sl < 8; ++sl) {
-                lens[sl] = 0u;
                 const uint32_t j = (childOf >> (4 * sl)) & 0xFu;
                 if (j == 0xFu)
                     continue;
                 const uint32_t ref = s_ref[j][tid];
+                uint32_t len = 0u;
                 if (ref & LEAF) {
                     uint32_t k0, k1;
                     runOf(ref, k0, k1);
-                    lens[sl] = k1 - k0;
+                    len = k1 - k0;
+                    lds.len[j][tid] = len;
                 }
-                if ((ref & LEAF) && !splits(lens[sl])) {
+                if ((ref & LEAF) && !splits(len)) {
                     leafMask |= 1u << sl;
-                    ct += lens[sl];
+                    ct += len;
                 } else
                     imask |= 1u << sl;
             }
@@ -426,7 +426,6 @@ __device__ __forceinline__ void collapse_range(CollapseLds &lds, const CollapseA
         rec.triBase = triBase;
         uint32_t counts = 0, longest = 0;
         uint32_t rank = 0, run = 0;
-#pragma unroll
         for (int sl = 0; sl < 8; ++sl) {
             rec.off16[sl] = rec.cnt16[sl] = 0;
             const uint32_t j = (childOf >> (4 * sl)) & 0xFu;
@@ -441,7 +440,7 @@ __device__ __forceinline__ void collapse_range(CollapseLds &lds, const CollapseA
                 ++rank;
                 continue;
             }
-            const uint32_t len = lens[sl];
+            const uint32_t len = lds.len[j][tid];
             if (splits(len)) { // the slot keeps the leaf's box; its triangles hang one node further down
                 rootOf[childBase + rank] = RUN_FLAG | (ref & LEAF_MASK);
                 leafParent[ref & LEAF_MASK] = s_aux[j][tid];
@@ -564,7 +563,7 @@ __global__ __launch_bounds__(BT) void run_nodes_kernel(CollapseArgs args, const 
     store_record(args.out + w, rec);
 }
 
-__global__ __launch_bounds__(BT) void collapse_level_kernel(CollapseArgs args, int level) {
+__global__ __launch_bounds__(BT) __attribute__((amdgpu_waves_per_eu(4))) void collapse_level_kernel(CollapseArgs args, int level) {
     __shared__ CollapseLds lds;
     const uint32_t start = args.ctl->bounds[level], end = args.ctl->bounds[level + 1];
     if (start >= end)
