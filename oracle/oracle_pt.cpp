@@ -91,7 +91,9 @@ inline vec3 LoadV3(const float *p, uint32_t i) { return {p[3 * i], p[3 * i + 1],
 // Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11).
 struct Rng {
     uint32_t seed, pixel, sample, draw;
-    float next() {
+    // four uniforms in (0, 1] (like curand_uniform): the words of one block; a sampling event of a path
+    // (pixel jitter, light sample, bounce) takes one block
+    void next4(float &u0, float &u1, float &u2, float &u3) {
         uint32_t c[4] = {draw++, sample, pixel, 0x4B4F5545u};
         uint32_t k[2] = {seed, 0xCAFEF00Du};
         for (int r = 0; r < 10; ++r) {
@@ -108,8 +110,10 @@ struct Rng {
             k[0] += 0x9E3779B9u;
             k[1] += 0xBB67AE85u;
         }
-        // (0, 1] like curand_uniform
-        return static_cast<float>((c[0] >> 8) + 1u) * 5.9604644775390625e-08f;
+        u0 = static_cast<float>((c[0] >> 8) + 1u) * 5.9604644775390625e-08f;
+        u1 = static_cast<float>((c[1] >> 8) + 1u) * 5.9604644775390625e-08f;
+        u2 = static_cast<float>((c[2] >> 8) + 1u) * 5.9604644775390625e-08f;
+        u3 = static_cast<float>((c[3] >> 8) + 1u) * 5.9604644775390625e-08f;
     }
 };
 
@@ -247,8 +251,8 @@ vec3 renderScene(const Scene &s, Rng &rng, Ray ray) {
         vec3 Li = V3(0.f);
         for (uint32_t li = 0; li < s.lightNum; ++li) {
             const Light &lht = s.lights[li];
-            float u0 = rng.next();
-            float u1 = rng.next();
+            float u0, u1, unused2, unused3;
+            rng.next4(u0, u1, unused2, unused3);
             LightSample ls = SampleLight(lht, u0, u1, ray.pos);
             ls.pos += Eps * ls.norm;
             vec3 in = ls.pos - ray.pos;
@@ -265,9 +269,8 @@ vec3 renderScene(const Scene &s, Rng &rng, Ray ray) {
         }
 
         float pdfIndrct;
-        float u = rng.next();
-        float u0 = rng.next();
-        float u1 = rng.next();
+        float u, u0, u1, uRoulette;
+        rng.next4(u, u0, u1, uRoulette);
         if (u <= matr.kdOverKdAddKs) {
             vec3 tngnt = GenerateTangent(norm);
             ray.dir = CosineThetaPhiToDirection(std::sqrt(1.f - u0), TwoPi * u1, norm, tngnt);
@@ -284,8 +287,7 @@ vec3 renderScene(const Scene &s, Rng &rng, Ray ray) {
         Lo += throughout * Li;
         throughout *= dot(ray.dir, norm) / pdfIndrct / RR * BRDF(matr, ray.dir, dirOut, norm);
 
-        u = rng.next();
-        if (u > RR && depth > 1)
+        if (uRoulette > RR && depth > 1)
             break;
     }
     // HDRToLDRCorrect + GammaCorrect, include/cg/math.h:75-93
@@ -540,8 +542,10 @@ void ko_pt_render_sample(const ko_pt_scene *sc, float *accum, uint8_t *rgba, int
             Ray eyeRay;
             {
                 vec4 tmp;
-                tmp.x = 1.f - rng.next() + x;
-                tmp.y = 1.f - rng.next() + y;
+                float jx, jy, unused2, unused3;
+                rng.next4(jx, jy, unused2, unused3);
+                tmp.x = 1.f - jx + x;
+                tmp.y = 1.f - jy + y;
                 tmp.z = static_cast<float>(W);
                 tmp.w = static_cast<float>(H);
                 tmp.x = (2.f * tmp.x - tmp.z) / tmp.z;
@@ -628,8 +632,12 @@ void ko_rt_render_target(const ko_pt_scene *sc, const float *rootAABB6, int disp
 // The generator on its own, so that the device implementation can be checked value for value.
 void ko_rng_uniforms(uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t count, float *out) {
     Rng rng{seed, pixel, sample, 0};
-    for (uint32_t i = 0; i < count; ++i)
-        out[i] = rng.next();
+    for (uint32_t i = 0; i < count; i += 4) {
+        float u[4];
+        rng.next4(u[0], u[1], u[2], u[3]);
+        for (uint32_t j = 0; j < 4 && i + j < count; ++j)
+            out[i + j] = u[j];
+    }
 }
 
 } // extern "C"

@@ -8,8 +8,9 @@
 // nearer than the light" (:381-383 compares the closest t with the distance), so they stop at the
 // first such triangle.
 // Random numbers: the reference draws from cuRAND XORWOW, curand_init(1234, pixel, 0); cuRAND does not
-// exist on this platform, so a counter-based Philox4x32-10 keyed by (seed; draw, sample, pixel) is used,
-// drawn in the reference's order, which also makes a pixel's stream independent of how the image is
+// exist on this platform, so a counter-based Philox4x32-10 keyed by (seed; event, sample, pixel) is used -
+// one block of four uniforms per sampling event (pixel jitter, light sample, bounce), its words used in
+// the reference's order of draws - which also makes a pixel's stream independent of how the image is
 // split between GPUs.
 #include "kk_host.h"
 #include "traverse.h"
@@ -30,7 +31,10 @@ constexpr float OneOverTwoPi = 0.159154943091895335768883763372514362f;
 
 struct Rng {
     uint32_t seed, pixel, sample, draw;
-    KK_D float next() {
+    // The next four uniforms in (0, 1]: the four words of one Philox4x32-10 block. A sampling event of a
+    // path - the pixel jitter, a light sample, a bounce - takes one block and uses its words in the
+    // reference's order of draws.
+    KK_D void next4(float &u0, float &u1, float &u2, float &u3) {
         uint32_t c0 = draw++, c1 = sample, c2 = pixel, c3 = 0x4B4F5545u;
         uint32_t k0 = seed, k1 = 0xCAFEF00Du;
 #pragma unroll
@@ -46,7 +50,10 @@ struct Rng {
             k0 += 0x9E3779B9u;
             k1 += 0xBB67AE85u;
         }
-        return static_cast<float>((c0 >> 8) + 1u) * 5.9604644775390625e-08f; // (0, 1]
+        u0 = static_cast<float>((c0 >> 8) + 1u) * 5.9604644775390625e-08f;
+        u1 = static_cast<float>((c1 >> 8) + 1u) * 5.9604644775390625e-08f;
+        u2 = static_cast<float>((c2 >> 8) + 1u) * 5.9604644775390625e-08f;
+        u3 = static_cast<float>((c3 >> 8) + 1u) * 5.9604644775390625e-08f;
     }
 };
 
@@ -221,8 +228,8 @@ KK_D f3 renderScene(const Tracer &tracer, const kk_pt_scene &p, Rng &rng, Ray ra
         f3 Li = F3(0.f);
         for (uint32_t li = 0; li < p.light_num; ++li) {
             const kk_light lht = p.lights[li];
-            const float u0 = rng.next();
-            const float u1 = rng.next();
+            float u0, u1, unused2, unused3;
+            rng.next4(u0, u1, unused2, unused3);
             LightSample ls = SampleLight(lht, u0, u1, ray.pos);
             ls.pos = ls.pos + Eps * ls.norm;
             const f3 in = ls.pos - ray.pos;
@@ -238,9 +245,8 @@ KK_D f3 renderScene(const Tracer &tracer, const kk_pt_scene &p, Rng &rng, Ray ra
         }
 
         float pdfIndrct;
-        float u = rng.next();
-        const float u0 = rng.next();
-        const float u1 = rng.next();
+        float u, u0, u1, uRoulette;
+        rng.next4(u, u0, u1, uRoulette);
         if (u <= matr.kd_over_kd_add_ks) {
             const f3 tngnt = GenerateTangent(norm);
             ray.dir = CosineThetaPhiToDirection(sqrtf(1.f - u0), TwoPi * u1, norm, tngnt);
@@ -257,8 +263,7 @@ KK_D f3 renderScene(const Tracer &tracer, const kk_pt_scene &p, Rng &rng, Ray ra
         Lo = Lo + throughout * Li;
         throughout = throughout * (dot(ray.dir, norm) / pdfIndrct / RR * BRDF(matr, ray.dir, dirOut, norm));
 
-        u = rng.next();
-        if (u > RR && depth > 1)
+        if (uRoulette > RR && depth > 1)
             break;
     }
     // HDRToLDRCorrect + GammaCorrect, include/cg/math.h:75-93
@@ -299,8 +304,10 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(5, 5)))
         for (int c = 0; c < 3; ++c)
             rot.c[c] = {f.eye_rot[3 * c], f.eye_rot[3 * c + 1], f.eye_rot[3 * c + 2]};
         f4 tmp;
-        tmp.x = 1.f - rng.next() + x;
-        tmp.y = 1.f - rng.next() + y;
+        float jx, jy, unused2, unused3;
+        rng.next4(jx, jy, unused2, unused3);
+        tmp.x = 1.f - jx + x;
+        tmp.y = 1.f - jy + y;
         tmp.z = static_cast<float>(W);
         tmp.w = static_cast<float>(H);
         tmp.x = (2.f * tmp.x - tmp.z) / tmp.z;
@@ -384,25 +391,6 @@ constexpr uint32_t COUNTER_SLOTS = 64;
 // are in flight on one GPU at once.)
 static __device__ uint32_t g_pixelQueue[COUNTER_SLOTS * 32];
 
-// The acceptance test of a walk's final hit (see trace_accel.hip): the ray must pass the reference's slab
-// test of the box of the hit triangle's leaf's parent. The triangle's own box lies inside that box and
-// the test is monotonic in the box, so a pass there settles it without loading the parent node.
-__device__ __forceinline__ bool final_hit_passes(const kk_lbvh_node *__restrict__ nodes,
-                                                 const accel::TriRec *__restrict__ recs, uint32_t w,
-                                                 const accel::RayState &ray) {
-    const uint4 *tp = reinterpret_cast<const uint4 *>(recs + w);
-    const uint4 a = tp[0], b = tp[1], c = tp[2];
-    const f3 v0 = F3(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z));
-    const f3 v1 = F3(__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z));
-    const f3 v2 = F3(__uint_as_float(c.x), __uint_as_float(c.y), __uint_as_float(c.z));
-    AABB tb;
-    tb.minPos = {fminf(fminf(v0.x, v1.x), v2.x), fminf(fminf(v0.y, v1.y), v2.y), fminf(fminf(v0.z, v1.z), v2.z)};
-    tb.maxPos = {fmaxf(fmaxf(v0.x, v1.x), v2.x), fmaxf(fmaxf(v0.y, v1.y), v2.y), fmaxf(fmaxf(v0.z, v1.z), v2.z)};
-    if (accel::passes_box(tb, ray))
-        return true;
-    return accel::passes_parent(nodes, b.w, ray);
-}
-
 struct PathState {
     // the path
     uint32_t pixel;  // y * W + x
@@ -426,7 +414,8 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(KK_PT_W
     __shared__ uint32_t s_stack[LANE_LDS_DEPTH * THREADS];
     __shared__ unsigned short s_bits[LANE_LDS_DEPTH * THREADS];
     __shared__ unsigned long long s_key[THREADS]; // pooled triangle test: an owner's best (t, sorted position) ...
-    __shared__ uint32_t s_mark[THREADS];          // ... and which lane's triangles start at a pair
+    __shared__ uint32_t s_mark[THREADS];          // ... which lane's triangles start at a pair ...
+    __shared__ uint32_t s_rec[THREADS];           // ... and the record of an owner's winning triangle
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const unsigned long long lanesBelow = (1ull << lane) - 1ull;
@@ -454,6 +443,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(KK_PT_W
     LaneWalk w{};
     uint32_t pendW = 0u, pendC = 0u;
     Hit8 best{};
+    float rayFar = 0.f; // where the lane's ray ends (a shadow ray: just before the light)
 
     unsigned long long cntPasses = 0, cntWalkLanes = 0, cntShades = 0, cntShadeLanes = 0, cntRays = 0,
                        cntVisits = 0, cntTris = 0, cntRounds = 0, cntPairs = 0, cntExact = 0;
@@ -461,7 +451,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(KK_PT_W
     auto start_ray = [&](f3 pos, f3 dir, bool closest, float tMax) {
         if (COUNT)
             ++cntRays;
-        best.t = closest ? FloatMax : tMax;
+        best.t = rayFar = closest ? FloatMax : tMax;
         best.bx = best.by = 0.f;
         best.fi = best.k = best.w = 0xFFFFFFFFu;
         best.sure = false;
@@ -469,8 +459,6 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(KK_PT_W
         float tEnter, tExit;
         HitAABB(Ray{pos, dir}, rootBox, tEnter, tExit);
         prepare_ray(pos, dir, ray, sg, mode);
-        if (!closest && mode == MODE_FAST)
-            mode = MODE_CAREFUL; // a shadow ray checks every candidate as it meets it
         w.start(sg.oct);
         if (tEnter > tExit)
             stage = closest ? ST_DONE_C : ST_DONE_S_CLEAR;
@@ -570,11 +558,12 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(KK_PT_W
             // lanes with work do not hold the other lanes up for a pass per triangle.
             while (__ballot((stage == ST_WALK_C || stage == ST_WALK_S) && pendC != 0u) != 0ull) {
                 uint32_t tested = 0u, pairs = 0u;
-                const bool won = pooled_round<COUNT, false, false>(
-                    view.recs, nodes, view.parents, s_key + (tid & ~63), s_mark + (tid & ~63), lane, ray, mode,
-                    stage == ST_WALK_C, stage == ST_WALK_C || stage == ST_WALK_S, pendW, pendC, best, tested, pairs);
+                const bool won = pooled_round<COUNT>(view.recs, nodes, view.parents, s_key + (tid & ~63),
+                                                     s_rec + (tid & ~63), s_mark + (tid & ~63), lane, ray, mode,
+                                                     stage == ST_WALK_C, stage == ST_WALK_C || stage == ST_WALK_S,
+                                                     pendW, pendC, best.t, best.k, best.w, tested, pairs);
                 if (won && stage == ST_WALK_S)
-                    stage = ST_DONE_S_HIT;
+                    stage = ST_DONE_S_HIT; // any hit ends a shadow walk
                 if (COUNT) {
                     ++cntRounds;
                     cntPairs += pairs;
@@ -588,18 +577,36 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(KK_PT_W
             break;
 
         // ================= shade: every lane takes its path to its next ray =============================
-        // A closest-hit walk in the fast mode took its hits unchecked: the final one must pass the test of
-        // its leaf's parent box, else the lane walks the ray again, checking every hit as it meets it
-        // (and consumes nothing this time round).
-        if (stage == ST_DONE_C && best.fi != 0xFFFFFFFFu && mode == MODE_FAST &&
-            !final_hit_passes(nodes, view.recs, best.w, ray)) {
-            mode = MODE_CAREFUL;
-            best.t = FloatMax;
-            best.bx = best.by = 0.f;
-            best.fi = best.k = best.w = 0xFFFFFFFFu;
-            pendC = 0u;
-            w.start(sg.oct);
-            stage = ST_WALK_C;
+        // A walk in the fast mode took its hits unchecked and kept only (t, sorted position, record) of
+        // the best. The hit must pass the test of its leaf's parent box (the triangle's own box lies inside
+        // that box and the test is monotonic in the box, so a pass there settles it without loading the
+        // parent node), else the lane walks the ray again, checking every hit as it meets it, and consumes
+        // nothing this time round. A closest hit that stands gets its distance and barycentrics from the
+        // reference's test of that one triangle.
+        if ((stage == ST_DONE_C || stage == ST_DONE_S_HIT) && best.w != 0xFFFFFFFFu) {
+            const uint4 *tp = reinterpret_cast<const uint4 *>(view.recs + best.w);
+            const uint4 a = tp[0], b = tp[1], c = tp[2];
+            const f3 v0 = F3(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z));
+            const f3 v1 = F3(__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z));
+            const f3 v2 = F3(__uint_as_float(c.x), __uint_as_float(c.y), __uint_as_float(c.z));
+            bool ok = true;
+            if (mode == MODE_FAST) {
+                AABB tb;
+                tb.minPos = {fminf(fminf(v0.x, v1.x), v2.x), fminf(fminf(v0.y, v1.y), v2.y), fminf(fminf(v0.z, v1.z), v2.z)};
+                tb.maxPos = {fmaxf(fmaxf(v0.x, v1.x), v2.x), fmaxf(fmaxf(v0.y, v1.y), v2.y), fmaxf(fmaxf(v0.z, v1.z), v2.z)};
+                ok = passes_box(tb, ray) || passes_parent(nodes, b.w, ray);
+            }
+            if (!ok) {
+                mode = MODE_CAREFUL;
+                best.t = rayFar;
+                best.k = best.w = 0xFFFFFFFFu;
+                pendC = 0u;
+                w.start(sg.oct);
+                stage = stage == ST_DONE_C ? ST_WALK_C : ST_WALK_S;
+            } else if (stage == ST_DONE_C) {
+                best.t = HitTriangle(Ray{ray.pos, ray.dir}, v0, v1, v2, best.bx, best.by);
+                best.fi = a.w;
+            }
         }
         consume_walk();
         // light samples until the lane has a shadow ray out or is through its lights (:353-380)
@@ -614,8 +621,8 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(KK_PT_W
             if (stage == ST_LIGHTS && ps.li < p.light_num) {
                 Rng rng{seed, ps.pixel, sample, ps.draw};
                 const kk_light lht = p.lights[ps.li];
-                const float u0 = rng.next();
-                const float u1 = rng.next();
+                float u0, u1, unused2, unused3;
+                rng.next4(u0, u1, unused2, unused3);
                 ps.draw = rng.draw;
                 LightSample ls = SampleLight(lht, u0, u1, ray.pos);
                 ls.pos = ls.pos + Eps * ls.norm;
@@ -643,9 +650,8 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(KK_PT_W
                 const kk_material matr = p.materials[ps.grp];
                 Rng rng{seed, ps.pixel, sample, ps.draw};
                 float pdfIndrct;
-                float u = rng.next();
-                const float u0 = rng.next();
-                const float u1 = rng.next();
+                float u, u0, u1, uRoulette;
+                rng.next4(u, u0, u1, uRoulette);
                 if (u <= matr.kd_over_kd_add_ks) {
                     const f3 tngnt = GenerateTangent(ps.norm);
                     ray.dir = CosineThetaPhiToDirection(sqrtf(1.f - u0), TwoPi * u1, ps.norm, tngnt);
@@ -662,9 +668,8 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(KK_PT_W
                 ps.Lo = ps.Lo + ps.throughout * ps.Li;
                 ps.throughout = ps.throughout *
                                 (dot(ray.dir, ps.norm) / pdfIndrct / RR * BRDF(matr, ray.dir, ps.dirOut, ps.norm));
-                u = rng.next();
                 ps.draw = rng.draw;
-                const bool roulette = u > RR && ps.depth > 1u;
+                const bool roulette = uRoulette > RR && ps.depth > 1u;
                 ++ps.depth;
                 if (!roulette && ps.depth < p.max_path_depth &&
                     gmax(ps.throughout.x, gmax(ps.throughout.y, ps.throughout.z)) >= FloatEps)
@@ -731,8 +736,10 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(KK_PT_W
                             for (int c = 0; c < 3; ++c)
                                 rot.c[c] = {f.eye_rot[3 * c], f.eye_rot[3 * c + 1], f.eye_rot[3 * c + 2]};
                             f4 tmp;
-                            tmp.x = 1.f - rng.next() + x;
-                            tmp.y = 1.f - rng.next() + y;
+                            float jx, jy, unused2, unused3;
+                            rng.next4(jx, jy, unused2, unused3);
+                            tmp.x = 1.f - jx + x;
+                            tmp.y = 1.f - jy + y;
                             tmp.z = static_cast<float>(W);
                             tmp.w = static_cast<float>(H);
                             tmp.x = (2.f * tmp.x - tmp.z) / tmp.z;
@@ -797,8 +804,12 @@ __global__ void rng_uniforms_kernel(uint32_t seed, uint32_t pixel, uint32_t samp
                                     float *out) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         Rng rng{seed, pixel, sample, 0};
-        for (uint32_t i = 0; i < count; ++i)
-            out[i] = rng.next();
+        for (uint32_t i = 0; i < count; i += 4) {
+            float u[4];
+            rng.next4(u[0], u[1], u[2], u[3]);
+            for (uint32_t j = 0; j < 4 && i + j < count; ++j)
+                out[i + j] = u[j];
+        }
     }
 }
 

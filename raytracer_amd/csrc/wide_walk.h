@@ -299,28 +299,32 @@ __device__ __forceinline__ uint32_t wave_inclusive_max(uint32_t v) {
 // One round of the pooled triangle test; every lane of the wave calls it. A lane with `pendC` triangles
 // pending (records pendW ...) and `joins` set owns that many (ray, triangle) pairs; the pairs of all lanes,
 // in lane order, are numbered from 0 and pair i < 64 is tested by lane i with its owner's ray. An owner
-// ends up with what its own one-by-one loop (test_run) would keep - the smallest (t, sorted position)
-// among its pairs that are hit, not farther than its best and accepted under its mode - in `best`, and
-// the function returns true for it; pendW / pendC move past the pairs that were served (the rest wait
-// for the next round). closest == false (an any-hit ray): best.t is the ray's far end and only the
-// return value matters. SURE: also fill best.sure (a caller that checks its final hit some other way
-// leaves it out). waveKey / waveMark: 64 entries of LDS each, this wave's own.
-template <bool COUNT, bool WATERTIGHT, bool SURE>
+// ends up with the hit its own one-by-one loop (test_run) would keep - the smallest (t, sorted position)
+// among its pairs that are hit, not behind its best and accepted under its mode - as bestT (+0 for -0),
+// bestK and bestW (the triangle's record; barycentrics and face are for the caller to recompute from
+// it when the walk is over), and the function returns true for it. pendW / pendC move past the pairs
+// that were served (the rest wait for the next round). closest == false (an any-hit ray): bestT is the
+// ray's far end and any hit nearer than that is taken. waveKey / waveRec / waveMark: 64 entries of LDS
+// each, this wave's own.
+template <bool COUNT>
 __device__ __forceinline__ bool pooled_round(const TriRec *__restrict__ recs, const kk_lbvh_node *__restrict__ nodes,
                                              const uint32_t *__restrict__ parents,
-                                             unsigned long long *waveKey, uint32_t *waveMark, int lane,
-                                             const RayState &ray, uint32_t mode, bool closest, bool joins,
-                                             uint32_t &pendW, uint32_t &pendC, Hit8 &best, uint32_t &triTests,
-                                             uint32_t &pairsOut) {
+                                             unsigned long long *waveKey, uint32_t *waveRec, uint32_t *waveMark,
+                                             int lane, const RayState &ray, uint32_t mode, bool closest, bool joins,
+                                             uint32_t &pendW, uint32_t &pendC, float &bestT, uint32_t &bestK,
+                                             uint32_t &bestW, uint32_t &triTests, uint32_t &pairsOut) {
     const uint32_t c = joins ? (pendC < 64u ? pendC : 64u) : 0u;
     const uint32_t incl = wave_inclusive_sum(c);
     const uint32_t start = incl - c;
     const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
     pairsOut = total < 64u ? total : 64u;
     // owner of pair i = the last lane whose first pair is at or before i: every owner marks its first
-    // pair, a running maximum over the pairs spreads the marks
+    // pair, a running maximum over the pairs spreads the marks. An owner's word starts as its present
+    // best, so a pair that ties in t with a later sorted position loses by itself.
+    // (t >= 0: its bits order like the value; "+ 0" turns -0 into +0)
+    const unsigned long long before = (static_cast<unsigned long long>(__float_as_uint(bestT + 0.f)) << 32) | bestK;
     waveMark[lane] = 0u;
-    waveKey[lane] = ~0ull;
+    waveKey[lane] = before;
     __builtin_amdgcn_wave_barrier();
     if (c != 0u && start < 64u)
         waveMark[start] = static_cast<uint32_t>(lane);
@@ -332,32 +336,26 @@ __device__ __forceinline__ bool pooled_round(const TriRec *__restrict__ recs, co
     RayState oray;
     oray.pos = F3(fromF(ray.pos.x), fromF(ray.pos.y), fromF(ray.pos.z));
     oray.dir = F3(fromF(ray.dir.x), fromF(ray.dir.y), fromF(ray.dir.z));
-    const float oT = fromF(best.t);
-    const uint32_t oK = fromU(best.k);
+    const float oT = fromF(bestT);
     const uint32_t rec = fromU(pendW - start) + static_cast<uint32_t>(lane);
     const uint32_t oFlags = fromU(mode | (closest ? 0x100u : 0u));
     const uint32_t oMode = oFlags & 0xffu;
     const bool oClosest = (oFlags & 0x100u) != 0u;
     unsigned long long key = ~0ull;
-    float t = 0.f, bx = 0.f, by = 0.f;
-    uint32_t fi = 0u;
-    f3 v0 = F3(0.f), v1 = F3(0.f), v2 = F3(0.f);
     if (pairOn) {
         const uint4 *tp = reinterpret_cast<const uint4 *>(recs + rec);
         const uint4 a = tp[0], b = tp[1], cc = tp[2];
-        v0 = F3(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z));
-        v1 = F3(__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z));
-        v2 = F3(__uint_as_float(cc.x), __uint_as_float(cc.y), __uint_as_float(cc.z));
-        t = WATERTIGHT ? hit_watertight_banded(make_shear(oray.dir), oray.pos, oray.dir, v0, v1, v2, bx, by)
-                       : HitTriangle(Ray{oray.pos, oray.dir}, v0, v1, v2, bx, by);
-        fi = a.w;
-        bool cand = t >= 0.f && (t < oT || (oClosest && t == oT && cc.w < oK));
+        const f3 v0 = F3(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z));
+        const f3 v1 = F3(__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z));
+        const f3 v2 = F3(__uint_as_float(cc.x), __uint_as_float(cc.y), __uint_as_float(cc.z));
+        float bx, by;
+        const float t = HitTriangle(Ray{oray.pos, oray.dir}, v0, v1, v2, bx, by);
+        bool cand = t >= 0.f && (oClosest ? t <= oT : t < oT);
         if (cand && oMode != MODE_FAST) {
             oray.inv = 1.f / oray.dir; // (a ray with a zero component is in MODE_CHAIN, which divides)
             cand = oMode == MODE_CAREFUL ? passes_parent(nodes, b.w, oray) : passes_chain(nodes, parents, b.w, oray);
         }
         if (cand) {
-            // t >= 0: its bits order like the value ("+ 0" turns -0 into +0)
             key = (static_cast<unsigned long long>(__float_as_uint(t + 0.f)) << 32) | cc.w;
             atomicMin(&waveKey[own], key);
         }
@@ -368,37 +366,20 @@ __device__ __forceinline__ bool pooled_round(const TriRec *__restrict__ recs, co
     pendW += served;
     pendC -= served;
     if (__ballot(key != ~0ull) == 0ull)
-        return false; // no pair of this round is a hit its owner would take
+        return false; // no pair of this round is a hit its owner might take
     __builtin_amdgcn_wave_barrier();
-    // the owner's winning pair hands over its hit
-    const bool winner = key != ~0ull && waveKey[own] == key;
-    float sure = 0.f;
-    if (SURE && winner && oMode == MODE_FAST && oClosest) { // (see Hit8::sure)
-        AABB tb;
-        tb.minPos = {fminf(fminf(v0.x, v1.x), v2.x), fminf(fminf(v0.y, v1.y), v2.y), fminf(fminf(v0.z, v1.z), v2.z)};
-        tb.maxPos = {fmaxf(fmaxf(v0.x, v1.x), v2.x), fmaxf(fmaxf(v0.y, v1.y), v2.y), fmaxf(fmaxf(v0.z, v1.z), v2.z)};
-        oray.inv = 1.f / oray.dir;
-        sure = passes_box(tb, oray) ? 1.f : 0.f;
-    }
-    const unsigned long long winners = __ballot(winner);
-    const unsigned long long mine =
-        served == 0u ? 0ull : ((served == 64u ? ~0ull : ((1ull << served) - 1ull)) << (start & 63u));
-    const int win = __ffsll(static_cast<long long>(winners & mine)) - 1;
-    const int src = win < 0 ? lane : win;
-    const float wt = __shfl(t, src, 64), wbx = __shfl(bx, src, 64), wby = __shfl(by, src, 64);
-    const float wsure = SURE ? __shfl(sure, src, 64) : 0.f;
-    const uint32_t wfi = static_cast<uint32_t>(__shfl(static_cast<int>(fi), src, 64));
-    if (win >= 0 && closest) {
-        best.t = wt;
-        best.bx = wbx;
-        best.by = wby;
-        best.fi = wfi;
-        best.k = static_cast<uint32_t>(waveKey[lane]);
-        best.w = pendW - served + (static_cast<uint32_t>(win) - start);
-        best.sure = wsure != 0.f;
+    if (key != ~0ull && waveKey[own] == key)
+        waveRec[own] = rec; // (sorted positions are unique: one pair writes)
+    __builtin_amdgcn_wave_barrier();
+    const unsigned long long now = waveKey[lane];
+    const bool won = c != 0u && now != before;
+    if (won) {
+        bestT = __uint_as_float(static_cast<uint32_t>(now >> 32));
+        bestK = static_cast<uint32_t>(now);
+        bestW = waveRec[lane];
     }
     __builtin_amdgcn_wave_barrier();
-    return win >= 0;
+    return won;
 }
 
 // ---- one ray -----------------------------------------------------------------------------------------
