@@ -379,7 +379,9 @@ enum : uint32_t {
     ST_DONE_S_HIT = 4, // shadow ray blocked
     ST_DONE_S_CLEAR = 5,
     ST_LIGHTS = 6, // choosing the next light that needs a shadow ray, or the path's next direction
-    ST_END = 7     // path over: pixel to be written
+    ST_END = 7,    // path over: pixel to be written
+    ST_LAUNCH_C = 8, // a closest-hit ray (ray.pos, ray.dir) waits to be set up ...
+    ST_LAUNCH_S = 9  // ... a shadow ray that ends at rayFar
 };
 
 #ifndef KK_PT_WAVES
@@ -635,7 +637,8 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(KK_PT_W
                     ++ps.li;
                 else {
                     ps.fOverPdf = factor / ls.pdf;
-                    start_ray(ray.pos, ray.dir, false, sqrtf(sqrIn) - Eps);
+                    rayFar = sqrtf(sqrIn) - Eps;
+                    stage = ST_LAUNCH_S;
                 }
             }
         }
@@ -673,7 +676,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(KK_PT_W
                 ++ps.depth;
                 if (!roulette && ps.depth < p.max_path_depth &&
                     gmax(ps.throughout.x, gmax(ps.throughout.y, ps.throughout.z)) >= FloatEps)
-                    start_ray(ray.pos, ray.dir, true, 0.f);
+                    stage = ST_LAUNCH_C;
                 else
                     stage = ST_END;
             }
@@ -757,15 +760,20 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(KK_PT_W
                             ps.throughout = F3(1.f);
                             ps.Lo = F3(0.f);
                             // renderScene's loop test before the first bounce (:318-320)
-                            if (p.max_path_depth > 0)
-                                start_ray(F3(pp.x, pp.y, pp.z), dir, true, 0.f);
-                            else
+                            if (p.max_path_depth > 0) {
+                                ray.pos = F3(pp.x, pp.y, pp.z);
+                                ray.dir = dir;
+                                stage = ST_LAUNCH_C;
+                            } else
                                 stage = ST_END;
                         }
                     }
                 }
             }
         }
+        // the rays the sections above asked for are set up together
+        if (stage == ST_LAUNCH_C || stage == ST_LAUNCH_S)
+            start_ray(ray.pos, ray.dir, stage == ST_LAUNCH_C, rayFar);
         lap(tcEnd);
     }
     if (COUNT) {
