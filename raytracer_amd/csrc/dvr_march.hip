@@ -260,7 +260,11 @@ struct InLeaf {
     float tCurr, tExit;
 };
 
-template <typename T, bool COUNT, bool SHADING>
+// AFIX: the atlas brick's edge in voxels when it is known at compile time (36 = 32-voxel leaves with the
+// two-voxel apron of a depth-box VDB, the layout of the reference's data sets), 0 = read from the
+// parameters. With a constant edge the eight taps of a sample are one address and seven immediate
+// offsets.
+template <typename T, bool COUNT, bool SHADING, int AFIX>
 __global__ __launch_bounds__(THREADS) void dvr_kernel(const kk_vdb_device_data vdb,
                                                       const float *__restrict__ tf,
                                                       const kk_dvr_params rp, const kk_dvr_frame fr,
@@ -289,7 +293,7 @@ __global__ __launch_bounds__(THREADS) void dvr_kernel(const kk_vdb_device_data v
         const kk_vdb_node *__restrict__ nodePools = vdb.node_pools;
         const uint32_t *__restrict__ childPools = vdb.child_pools;
         const T *__restrict__ atlas = static_cast<const T *>(vdb.atlas);
-        const int A = p.vox_per_atlas_brick;
+        const int A = AFIX ? AFIX : p.vox_per_atlas_brick;
         const size_t brickVox = static_cast<size_t>(A) * A * A;
         const bool useDepthBox = p.apron_dep_wid != p.apron_wid;
         const f3 voxPerVol = {p.vox_per_vol[0], p.vox_per_vol[1], p.vox_per_vol[2]};
@@ -1059,21 +1063,27 @@ int launch(const kk_vdb_device_data *h_vdb, const float *d_tf, const kk_dvr_para
         return KK_OK;
     dim3 grid(div_up(width, 16), div_up(stripes - stripeFirst, stripeStride));
     // the shading branch is a compile-time variant, like the reference's renderScene<T, ., UseShading>
-#define KK_LAUNCH_DVR(COUNT, SHADING)                                                              \
-    dvr_kernel<T, COUNT, SHADING><<<grid, THREADS, 0, stream>>>(*h_vdb, d_tf, *h_params, *h_frame, d_rgba, \
-                                                                width, height, y0, y1, stripeFirst,       \
-                                                                stripeStride, compact, d_counters)
+#define KK_LAUNCH_DVR(COUNT, SHADING, AFIX)                                                        \
+    dvr_kernel<T, COUNT, SHADING, AFIX><<<grid, THREADS, 0, stream>>>(                             \
+        *h_vdb, d_tf, *h_params, *h_frame, d_rgba, width, height, y0, y1, stripeFirst, stripeStride, compact, \
+        d_counters)
     const bool shading = h_params->use_shading != 0;
+    const bool edge36 = h_vdb->vdb_param.vox_per_atlas_brick == 36;
     if (d_counters) {
         if (shading)
-            KK_LAUNCH_DVR(true, true);
+            KK_LAUNCH_DVR(true, true, 0);
         else
-            KK_LAUNCH_DVR(true, false);
+            KK_LAUNCH_DVR(true, false, 0);
+    } else if (edge36) {
+        if (shading)
+            KK_LAUNCH_DVR(false, true, 36);
+        else
+            KK_LAUNCH_DVR(false, false, 36);
     } else {
         if (shading)
-            KK_LAUNCH_DVR(false, true);
+            KK_LAUNCH_DVR(false, true, 0);
         else
-            KK_LAUNCH_DVR(false, false);
+            KK_LAUNCH_DVR(false, false, 0);
     }
 #undef KK_LAUNCH_DVR
     KK_LAUNCH_CHECK();

@@ -5,7 +5,7 @@ import sys
 
 src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/summary_pmc_all.json"
 d = json.load(open(src))
-name = next(k for k in d if "dvr_kernel<unsigned char, false, false>" in k)
+name = next(k for k in d if "dvr_kernel<unsigned char, false, false" in k)
 c = d[name]
 cycles = c["GRBM_GUI_ACTIVE"] / 8  # the counter sums the 8 XCDs
 simds, cus = 1024, 256
