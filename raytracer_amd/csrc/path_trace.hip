@@ -365,10 +365,12 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(5, 5)))
 // lanes at triangles costs the wave a pass per triangle. Shade: when no lane walks any more, every lane
 // consumes its walk's result (hit -> material, normal; shadow answer -> add the light), samples lights
 // until one needs a shadow ray, or samples the path's next direction, and lanes whose path ended write
-// their pixel and take the next pixels of the queue with one ballot + one atomic per wave - so each
-// section of the shading code runs once per phase with every lane that needs it. A lane computes its
-// path with the same operations in the same order as renderScene above, and the random stream is keyed
-// by (pixel, sample, draw), so the image does not depend on the scheduling.
+// their pixel and take the next pixels of the queue with one ballot + one atomic per wave. Each of these
+// sections runs at most once per phase, and only when half the wave waits for it (SECTION_MIN): the
+// lanes of a wave are at different places of their paths, and a section run for a handful of lanes
+// costs the wave as much as one run for all; the few wait a walk phase longer instead. A lane computes
+// its path with the same operations in the same order as renderScene above, and the random stream is
+// keyed by (pixel, sample, sampling event), so the image does not depend on the scheduling.
 namespace persist {
 
 enum : uint32_t {
@@ -387,6 +389,10 @@ enum : uint32_t {
 #ifndef KK_PT_WAVES
 #define KK_PT_WAVES 4 // resident waves per SIMD = workgroups per CU
 #endif
+// A section of the shading code (light sample, next direction, pixel write + refill) runs for a wave when
+// at least this many of its lanes wait for it, or when no lane of the wave has a ray left to walk.
+// Measured on veach-mis 1080p: 1 -> 30.2 ms, 16 -> 26.2, 32 -> 24.8, 48 -> 28.3, 64 -> 30.9.
+constexpr int SECTION_MIN = 32;
 constexpr uint32_t COUNTER_SLOTS = 64;
 // Queue heads of the launches in flight: a launch takes the next slot and clears it on its stream
 // first. (Launches more than COUNTER_SLOTS apart share a slot; they cannot overlap unless that many
@@ -611,10 +617,14 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(KK_PT_W
             }
         }
         consume_walk();
+        // Each of the three sections below runs when enough lanes wait for it; lanes that are too few
+        // wait through the next walk phase (other lanes of the wave still have rays to walk, or the
+        // second turn of this loop takes everything that waits).
+        for (int force = 0; force < 2; ++force) {
         // light samples until the lane has a shadow ray out or is through its lights (:353-380)
         while (true) {
             const int nLights = __popcll(__ballot(stage == ST_LIGHTS && ps.li < p.light_num));
-            if (nLights == 0)
+            if (nLights == 0 || (!force && nLights < SECTION_MIN))
                 break;
             if (COUNT) {
                 ++cntShades;
@@ -644,12 +654,13 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(KK_PT_W
         }
         lap(tcLights);
         // after the last light: the path's next direction (:392-425)
-        if (__ballot(stage == ST_LIGHTS) != 0ull) {
+        const int nBounce = __popcll(__ballot(stage == ST_LIGHTS && ps.li >= p.light_num));
+        if (nBounce != 0 && (force || nBounce >= SECTION_MIN)) {
             if (COUNT) {
                 ++cntShades;
-                cntShadeLanes += __popcll(__ballot(stage == ST_LIGHTS));
+                cntShadeLanes += nBounce;
             }
-            if (stage == ST_LIGHTS) {
+            if (stage == ST_LIGHTS && ps.li >= p.light_num) {
                 const kk_material matr = p.materials[ps.grp];
                 Rng rng{seed, ps.pixel, sample, ps.draw};
                 float pdfIndrct;
@@ -683,7 +694,9 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(KK_PT_W
         }
         lap(tcBounce);
         // finished paths leave, new pixels come in
-        if (__ballot(stage == ST_END || stage == ST_IDLE) != 0ull) {
+        const int nWaiting = __popcll(__ballot(stage == ST_END || stage == ST_IDLE));
+        if ((__ballot(stage == ST_END) != 0ull || (nWaiting != 0 && !poolEmpty)) &&
+            (force || nWaiting >= SECTION_MIN)) {
             if (COUNT) {
                 ++cntShades;
                 cntShadeLanes += __popcll(__ballot(stage == ST_END || stage == ST_IDLE));
@@ -770,6 +783,9 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(KK_PT_W
                     }
                 }
             }
+        }
+        if (__ballot(stage == ST_LAUNCH_C || stage == ST_LAUNCH_S || stage == ST_WALK_C || stage == ST_WALK_S) != 0ull)
+            break; // some lane has a ray to walk: the others can wait
         }
         // the rays the sections above asked for are set up together
         if (stage == ST_LAUNCH_C || stage == ST_LAUNCH_S)
