@@ -128,3 +128,89 @@ def test_render_without_lbvh_reports_and_returns(veach, capsys):
     tracer = RayTracer(DEV)
     tracer.Render(FrameBuffer(8, 8, DEV))
     assert "lbvh is not set" in capsys.readouterr().err
+
+
+def _synthetic_scene():
+    """A floor, a glossy tilted plate, a quad light, a sphere light stand-in and clusters of tiny
+    triangles that share a Morton cell: leaves of a few dozen triangles (which get a node of their own
+    in the trace-side tree) and of several hundred (tested 64 at a time)."""
+    from raytracer_amd import synthetic as syn
+    from raytracer_amd.data.mesh import ObjLight, QUAD, SPHERE
+    f32 = np.float32
+    tris, groups = [], []
+
+    def quad(a, b, c, d):
+        return [[a, b, c], [a, c, d]]
+
+    groups.append(quad([-2, 0, -2], [-2, 0, 2], [2, 0, 2], [2, 0, -2]))                 # 0 floor
+    groups.append(quad([-1.5, 0.1, -1.2], [-1.5, 1.4, -1.6], [0.2, 1.4, -1.6], [0.2, 0.1, -1.2]))  # 1 plate
+    groups.append(quad([-0.4, 2.0, -0.4], [0.4, 2.0, -0.4], [0.4, 2.0, 0.4], [-0.4, 2.0, 0.4]))    # 2 quad light
+    soup_pos, _ = syn.triangle_soup(660, half_extent=0.5, seed=77)
+    soup = soup_pos.reshape(-1, 3, 3)
+    cluster = []
+    for k in range(12):                                     # twelve leaves of 30 tiny triangles
+        centre = np.array([-1.2 + 0.2 * k, 0.3 + 0.05 * (k % 3), 0.6], f32)
+        cluster += list(soup[30 * k:30 * k + 30] * f32(6e-4) + centre)
+    cluster += list(soup[360:660] * f32(6e-4) + np.array([0.9, 0.5, -0.3], f32))  # one of 300
+    groups.append([t.tolist() for t in cluster])            # 3 clusters
+    big, _ = syn.triangle_soup(150, half_extent=0.25, seed=78)
+    groups.append((big.reshape(-1, 3, 3) * f32(2.0) + np.array([-1.0, 0.0, -1.0], f32)).tolist())  # 4 shards
+    positions, face_idx, normals, starts = [], [], [], []
+    for g in groups:
+        starts.append(len(face_idx))
+        for t in g:
+            t = np.asarray(t, f32)
+            n = np.cross(t[1] - t[0], t[2] - t[0])
+            n = n / max(np.linalg.norm(n), 1e-20)
+            base = len(positions)
+            positions += [t[0], t[1], t[2]]
+            normals.append(n.astype(f32))
+            face_idx.append([base, base + 1, base + 2])
+    F = len(face_idx)
+    G = len(groups)
+    kd = np.array([[.6, .6, .6], [.1, .1, .1], [0, 0, 0], [.7, .3, .2], [.2, .5, .7]], f32)
+    ks = np.array([[0, 0, 0], [.8, .8, .8], [0, 0, 0], [0, 0, 0], [.2, .2, .2]], f32)
+    ns = np.array([1, 60, 1, 1, 12], f32)
+    emission = np.zeros((G, 3), f32)
+    emission[2] = [17, 12, 4]
+    lights = [ObjLight(QUAD, np.array([17, 12, 4], f32), o=np.array([-0.4, 2.0, -0.4], f32),
+                       u=np.array([0.8, 0, 0], f32), v=np.array([0, 0, 0.8], f32)),
+              ObjLight(SPHERE, np.array([40, 40, 60], f32), o=np.array([1.5, 1.2, 1.0], f32), r=f32(0.1))]
+    return dict(positions=np.asarray(positions, f32), normals=np.asarray(normals, f32),
+                tex_coords=np.zeros((1, 2), f32),
+                face_position_indices=np.asarray(face_idx, np.uint32),
+                face_normal_indices=np.repeat(np.arange(F, dtype=np.uint32)[:, None], 3, axis=1),
+                face_tex_coord_indices=np.zeros((F, 3), np.uint32),
+                grp_start_face_indices=np.asarray(starts, np.uint32),
+                mat_kd=kd, mat_ks=ks, mat_tr=np.zeros((G, 3), f32), mat_ni=np.ones(G, f32), mat_ns=ns,
+                mat_emission=emission, obj_lights=lights,
+                cam_eye=np.array([0.3, 1.3, 3.2], f32), cam_lookat=np.array([0, 0.4, 0], f32),
+                cam_up=np.array([0, 1, 0], f32))
+
+
+def test_quad_light_and_long_leaves(oracle):
+    """A scene the reference's only data set does not cover: a quad light beside a sphere light, a glossy
+    lobe, and leaves of 30 and of hundreds of triangles. The compacting kernel on the 8-wide tree, the
+    one-pixel-per-lane kernel on the binary tree and the checker must agree."""
+    scene = _synthetic_scene()
+    W, H, spp = 160, 96, 3
+    ref_tree = oracle.lbvh_build(scene["positions"], scene["face_position_indices"])
+    runs = np.diff(np.append(ref_tree["compactedFaces"].astype(np.int64), scene["face_position_indices"].shape[0]))
+    assert ((runs >= 4) & (runs <= 120)).sum() >= 8 and runs.max() > 120
+    out = {}
+    for wide in (True, False):
+        tracer, arr, c, proj = _setup(scene, W, H)
+        tracer.use_trace_tree = wide
+        fb = FrameBuffer(W, H, DEV)
+        for _ in range(spp):
+            tracer.Render(fb)
+        torch.cuda.synchronize()
+        out[wide] = (tracer.d_accum.cpu().numpy(), fb.ReadBack())
+    assert out[True][0].tobytes() == out[False][0].tobytes()
+    assert out[True][1].tobytes() == out[False][1].tobytes()
+    ref, ref_img = _oracle_render(oracle, scene, arr, c, proj, W, H, spp)
+    got = out[True][0]
+    assert float((np.abs(got - ref).max(axis=2) > TOL).mean()) <= 2e-3
+    assert float(np.abs(got - ref).mean()) < 1e-4
+    lit = got.max(axis=2) > 0.02
+    assert 0.5 < float(lit.mean()) <= 1.0
