@@ -164,4 +164,29 @@ KK_HD float HitTriangle(const Ray &r, f3 v0, f3 v1, f3 v2, float &bx, float &by)
     return t;
 }
 
+// The same test with the same operations on the same operands, written without early exits: both signs
+// of the determinant share one evaluation of dist, u, perp and v. For code in which the lanes of a wave
+// test different triangles, where the branches above would each run for some lane.
+KK_HD float HitTriangleFlat(const Ray &r, f3 v0, f3 v1, f3 v2, float &bx, float &by) {
+    const f3 e1 = v1 - v0;
+    const f3 e2 = v2 - v0;
+    const f3 p = cross(r.dir, e2);
+    const float det = dot(e1, p);
+    const f3 dist = r.pos - v0;
+    const float u = dot(dist, p);
+    const f3 perp = cross(dist, e1);
+    const float v = dot(r.dir, perp);
+    const float uv = u + v;
+    const bool front = det > FloatEps, back = det < -FloatEps;
+    const bool inFront = !(u < 0.f || u > det) && !(v < 0.f || uv > det);
+    const bool inBack = !(u > 0.f || u < det) && !(v > 0.f || uv < det);
+    if (!((front && inFront) || (back && inBack)))
+        return -1.f;
+    const float inv = 1.f / det;
+    const float t = dot(e2, perp) * inv;
+    bx = u * inv;
+    by = v * inv;
+    return t;
+}
+
 } // namespace kk

@@ -249,7 +249,7 @@ __device__ __forceinline__ void test_run(const TriRec *__restrict__ recs,
         const f3 v1 = F3(__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z));
         const f3 v2 = F3(__uint_as_float(c.x), __uint_as_float(c.y), __uint_as_float(c.z));
         const float t = WATERTIGHT ? hit_watertight_banded(shear, r.pos, r.dir, v0, v1, v2, bx, by)
-                                   : HitTriangle(ray, v0, v1, v2, bx, by);
+                                   : HitTriangleFlat(ray, v0, v1, v2, bx, by);
         if (COUNT)
             ++triTests;
         if (t >= 0.f && (t < best.t || (t == best.t && c.w < best.k))) {
@@ -349,7 +349,7 @@ __device__ __forceinline__ bool pooled_round(const TriRec *__restrict__ recs, co
         const f3 v1 = F3(__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z));
         const f3 v2 = F3(__uint_as_float(cc.x), __uint_as_float(cc.y), __uint_as_float(cc.z));
         float bx, by;
-        const float t = HitTriangle(Ray{oray.pos, oray.dir}, v0, v1, v2, bx, by);
+        const float t = HitTriangleFlat(Ray{oray.pos, oray.dir}, v0, v1, v2, bx, by);
         bool cand = t >= 0.f && (oClosest ? t <= oT : t < oT);
         if (cand && oMode != MODE_FAST) {
             oray.inv = 1.f / oray.dir; // (a ray with a zero component is in MODE_CHAIN, which divides)
