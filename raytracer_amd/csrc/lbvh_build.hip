@@ -14,13 +14,11 @@
 #include "kk_host.h"
 #include "kk_math.h"
 
+#include "radix_hist.h"
+
 namespace kk {
-namespace rsort {
-int sort_pairs(uint32_t *keysA, uint32_t *keysB, uint32_t *valsA, uint32_t *valsB, bool iota,
-               uint32_t n, void *ws, size_t wsBytes, hipStream_t stream, uint32_t **errorFlagOut,
-               int passes);
-}
 extern "C" size_t kk_sort_workspace_bytes(uint32_t n);
+extern "C" size_t kk_sort_workspace_error_offset(uint32_t n);
 
 namespace lbvh {
 
@@ -166,37 +164,44 @@ __device__ __forceinline__ void store_box(float *p, const AABB &b) {
     p[5] = b.maxPos.z;
 }
 
-// lbvh.cu:136-170, one thread per face.
+// lbvh.cu:136-170, a thread per face; a workgroup takes every gridDim-th block of faces and counts the
+// digits of the codes it writes for the sort that follows (radix_hist.h).
+constexpr uint32_t MORTON_MAX_BLOCKS = 2048;
 __global__ __launch_bounds__(THREADS) void morton_kernel(const float *__restrict__ pos,
                                                          const uint32_t *__restrict__ tri,
                                                          uint32_t faceNum,
                                                          const BuildParams *__restrict__ params,
                                                          uint32_t *__restrict__ mortons,
-                                                         float *__restrict__ faceBoxes) {
-    const uint32_t fi = blockIdx.x * THREADS + threadIdx.x;
-    if (fi >= faceNum)
-        return;
+                                                         float *__restrict__ faceBoxes,
+                                                         uint32_t *__restrict__ ghist) {
+    __shared__ uint32_t s_hist[4 * rsort::HIST_RADIX];
+    rsort::hist_clear<4>(s_hist, threadIdx.x, THREADS);
     const f3 minPos = {params->minPos[0], params->minPos[1], params->minPos[2]};
     const f3 invDlt = {params->invDlt[0], params->invDlt[1], params->invDlt[2]};
-    AABB box = AABB::Initial();
-    box.Expand(load3(pos, tri[3ull * fi]));
-    box.Expand(load3(pos, tri[3ull * fi + 1]));
-    box.Expand(load3(pos, tri[3ull * fi + 2]));
-    // kept for the leaf boxes: gathering one box per sorted face later costs a third of the lines that
-    // gathering its indices and vertices again would. 32 bytes per face (two 16-byte pieces), so that a
-    // gathered box never straddles a 128-byte line
-    float4 *fb = reinterpret_cast<float4 *>(faceBoxes + 8ull * fi);
-    fb[0] = make_float4(box.minPos.x, box.minPos.y, box.minPos.z, box.maxPos.x);
-    fb[1] = make_float4(box.maxPos.y, box.maxPos.z, 0.f, 0.f);
-    f3 c = .5f * (box.minPos + box.maxPos);
-    c = (c - minPos) * invDlt;
-    c.x = gmin(gmax(c.x * 1024.f, 0.f), 1023.f);
-    c.y = gmin(gmax(c.y * 1024.f, 0.f), 1023.f);
-    c.z = gmin(gmax(c.z * 1024.f, 0.f), 1023.f);
-    const uint32_t cx = expand10BitsTo32(static_cast<uint32_t>(c.x));
-    const uint32_t cy = expand10BitsTo32(static_cast<uint32_t>(c.y));
-    const uint32_t cz = expand10BitsTo32(static_cast<uint32_t>(c.z));
-    mortons[fi] = cx * 4 + cy * 2 + cz;
+    for (uint32_t fi = blockIdx.x * THREADS + threadIdx.x; fi < faceNum; fi += gridDim.x * THREADS) {
+        AABB box = AABB::Initial();
+        box.Expand(load3(pos, tri[3ull * fi]));
+        box.Expand(load3(pos, tri[3ull * fi + 1]));
+        box.Expand(load3(pos, tri[3ull * fi + 2]));
+        // kept for the leaf boxes: gathering one box per sorted face later costs a third of the lines that
+        // gathering its indices and vertices again would. 32 bytes per face (two 16-byte pieces), so that a
+        // gathered box never straddles a 128-byte line
+        float4 *fb = reinterpret_cast<float4 *>(faceBoxes + 8ull * fi);
+        fb[0] = make_float4(box.minPos.x, box.minPos.y, box.minPos.z, box.maxPos.x);
+        fb[1] = make_float4(box.maxPos.y, box.maxPos.z, 0.f, 0.f);
+        f3 c = .5f * (box.minPos + box.maxPos);
+        c = (c - minPos) * invDlt;
+        c.x = gmin(gmax(c.x * 1024.f, 0.f), 1023.f);
+        c.y = gmin(gmax(c.y * 1024.f, 0.f), 1023.f);
+        c.z = gmin(gmax(c.z * 1024.f, 0.f), 1023.f);
+        const uint32_t cx = expand10BitsTo32(static_cast<uint32_t>(c.x));
+        const uint32_t cy = expand10BitsTo32(static_cast<uint32_t>(c.y));
+        const uint32_t cz = expand10BitsTo32(static_cast<uint32_t>(c.z));
+        const uint32_t code = cx * 4 + cy * 2 + cz;
+        mortons[fi] = code;
+        rsort::hist_add<4>(s_hist, code);
+    }
+    rsort::hist_flush<4>(s_hist, ghist, threadIdx.x, THREADS);
 }
 
 // ---- run heads: flag[i] = (i == 0) || key[i-1] != key[i]  (include/cuda/algorithm.h:11-21) ----------
@@ -714,7 +719,7 @@ inline Ws layout(uint32_t N, uint32_t flags) {
     w.sortWsBytes = kk_sort_workspace_bytes(N);
     w.sortWs = c.take(w.sortWsBytes);
     // the sort's error word sits right after its histogram and counters (radix_sort.hip: sort_ws)
-    w.pub.error_flag = w.sortWs + align_up(4 * 4 * 256) + align_up(4 * 4);
+    w.pub.error_flag = w.sortWs + kk_sort_workspace_error_offset(N);
     w.pub.total_bytes = c.off;
     return w;
 }
@@ -775,16 +780,23 @@ extern "C" int kk_lbvh_build(const float *d_positions, uint32_t vert_num,
     build_setup_kernel<<<1, THREADS, 0, stream>>>(partials, bgrid, N, d_faces, d_compacted, d_nodes,
                                                   params, d_out);
     KK_LAUNCH_CHECK();
-    morton_kernel<<<div_up(N, THREADS), THREADS, 0, stream>>>(d_positions, d_face_pos_idx, N, params,
-                                                              keys0, faceBoxes);
+    uint32_t *ghist = nullptr;
+    int rc = rsort::sort_prepare(b + w.sortWs, w.sortWsBytes, N, stream, &ghist);
+    if (rc != KK_OK)
+        return rc;
+    uint32_t mgrid = div_up(N, THREADS);
+    if (mgrid > MORTON_MAX_BLOCKS)
+        mgrid = MORTON_MAX_BLOCKS;
+    morton_kernel<<<mgrid, THREADS, 0, stream>>>(d_positions, d_face_pos_idx, N, params, keys0, faceBoxes,
+                                                 ghist);
     KK_LAUNCH_CHECK();
     if (flags & KK_LBVH_KEEP_STAGES)
         KK_HIP_TRY(hipMemcpyAsync(b + w.pub.unsorted_mortons, keys0, 4ull * N,
                                   hipMemcpyDeviceToDevice, stream));
 
     // payload = face index; four passes leave keys in keys0 and faces in d_faces
-    int rc = rsort::sort_pairs(keys0, keys1, d_faces, vals1, true, N, b + w.sortWs, w.sortWsBytes,
-                               stream, nullptr, 4);
+    rc = rsort::sort_pairs(keys0, keys1, d_faces, vals1, true, N, b + w.sortWs, w.sortWsBytes, stream,
+                           nullptr, 4, true);
     if (rc != KK_OK)
         return rc;
 

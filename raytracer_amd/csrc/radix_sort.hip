@@ -15,6 +15,7 @@
 //      each run of equal digits is written to consecutive addresses (coalesced stores).
 // HBM traffic per key: 4 B (histogram) + 4 x (8 B read + 8 B write) = 68 B.
 #include "kk_host.h"
+#include "radix_hist.h"
 
 #include <mutex>
 
@@ -34,6 +35,7 @@ constexpr uint32_t VALUE_MASK = 0x3FFFFFFFu;
 constexpr uint32_t SPIN_LIMIT = 1u << 22;
 
 static_assert(THREADS == RADIX, "thread d owns digit d");
+static_assert(RADIX == HIST_RADIX && HIST_COPY_STRIDE == PASSES * RADIX, "radix_hist.h describes these rows");
 
 __device__ __forceinline__ uint32_t ld_status(const uint32_t *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -101,7 +103,7 @@ __global__ __launch_bounds__(THREADS) void histogram_kernel(const uint32_t *__re
     for (int i = tid; i < PASSES * RADIX; i += THREADS) {
         uint32_t c = s_h[i];
         if (c)
-            atomicAdd(&ghist[i], c);
+            atomicAdd(&ghist[(blockIdx.x % HIST_COPIES) * HIST_COPY_STRIDE + i], c);
     }
 }
 
@@ -187,7 +189,11 @@ __global__ __launch_bounds__(THREADS) void onesweep_pass_kernel(
         }
         st_status(row, total | (tile == 0 ? FLAG_INC : FLAG_AGG));
         dstart = block_exclusive_scan(total, s_tmp, tid);
-        gstart = block_exclusive_scan(ghist[dg], s_tmp, tid);
+        uint32_t digitTotal = 0; // over the copies of the row (radix_hist.h)
+#pragma unroll
+        for (int c = 0; c < HIST_COPIES; ++c)
+            digitTotal += ghist[c * HIST_COPY_STRIDE + dg];
+        gstart = block_exclusive_scan(digitTotal, s_tmp, tid);
         s_digitStart[dg] = dstart;
     }
     __syncthreads();
@@ -264,7 +270,7 @@ inline SortWs sort_ws(uint32_t n) {
     SortWs w;
     Carver c;
     w.tiles = div_up(n, TILE);
-    w.ghist = c.take(sizeof(uint32_t) * PASSES * RADIX);
+    w.ghist = c.take(sizeof(uint32_t) * HIST_COPIES * HIST_COPY_STRIDE);
     w.counters = c.take(sizeof(uint32_t) * PASSES);
     w.error = c.take(sizeof(uint32_t));
     w.status = c.take(sizeof(uint32_t) * PASSES * static_cast<size_t>(w.tiles) * RADIX);
@@ -275,9 +281,22 @@ inline SortWs sort_ws(uint32_t n) {
 // Enqueues the whole sort. errorFlagOut (optional) receives the device address of the error word.
 // `passes` (1..4) sorts on the low 8 * passes key bits only; after an odd number of passes the result
 // is in the B arrays.
+// Clears the sort's workspace and names its histogram rows (row p = digit p, 256 words each), for a
+// caller whose own kernel counts the digits (radix_hist.h).
+int sort_prepare(void *ws, size_t wsBytes, uint32_t n, hipStream_t stream, uint32_t **ghistOut) {
+    SortWs w = sort_ws(n);
+    if (wsBytes < w.total) {
+        set_error("sort workspace too small: %zu < %zu", wsBytes, w.total);
+        return KK_ERR_WORKSPACE;
+    }
+    KK_HIP_TRY(hipMemsetAsync(ws, 0, w.total, stream));
+    *ghistOut = reinterpret_cast<uint32_t *>(static_cast<char *>(ws) + w.ghist);
+    return KK_OK;
+}
+
 int sort_pairs(uint32_t *keysA, uint32_t *keysB, uint32_t *valsA, uint32_t *valsB, bool iota,
                uint32_t n, void *ws, size_t wsBytes, hipStream_t stream, uint32_t **errorFlagOut,
-               int passes) {
+               int passes, bool prepared) {
     SortWs w = sort_ws(n);
     if (wsBytes < w.total) {
         set_error("sort workspace too small: %zu < %zu", wsBytes, w.total);
@@ -290,13 +309,15 @@ int sort_pairs(uint32_t *keysA, uint32_t *keysB, uint32_t *valsA, uint32_t *vals
     uint32_t *status = reinterpret_cast<uint32_t *>(b + w.status);
     if (errorFlagOut)
         *errorFlagOut = error;
-    // ghist, counters, error and the status rows are contiguous pieces of one allocation
-    KK_HIP_TRY(hipMemsetAsync(b, 0, w.total, stream));
+    if (!prepared) {
+        // ghist, counters, error and the status rows are contiguous pieces of one allocation
+        KK_HIP_TRY(hipMemsetAsync(b, 0, w.total, stream));
 
-    // every workgroup ends with up to 1024 atomics on the same 1024 words: few, long-running workgroups
-    const uint32_t hgrid = w.tiles < 512u ? (w.tiles ? w.tiles : 1u) : 512u;
-    histogram_kernel<<<hgrid, THREADS, 0, stream>>>(keysA, n, ghist);
-    KK_LAUNCH_CHECK();
+        // every workgroup ends with up to 1024 atomics on the same 1024 words: few, long-running workgroups
+        const uint32_t hgrid = w.tiles < 512u ? (w.tiles ? w.tiles : 1u) : 512u;
+        histogram_kernel<<<hgrid, THREADS, 0, stream>>>(keysA, n, ghist);
+        KK_LAUNCH_CHECK();
+    }
 
     uint32_t *kin = keysA, *kout = keysB, *vin = valsA, *vout = valsB;
     for (int p = 0; p < passes; ++p) {
@@ -335,7 +356,7 @@ constexpr size_t static_scratch_bytes(uint32_t n) {
     // what sort_ws() carves: ghist, counters and error word (one 256-byte aligned piece each), then
     // the status rows of all passes
     const size_t tiles = (static_cast<size_t>(n) + TILE - 1) / TILE;
-    return sizeof(uint32_t) * PASSES * RADIX + 256 + 256 + sizeof(uint32_t) * PASSES * tiles * RADIX;
+    return sizeof(uint32_t) * HIST_COPIES * HIST_COPY_STRIDE + 256 + 256 + sizeof(uint32_t) * PASSES * tiles * RADIX;
 }
 constexpr size_t STATIC_SCRATCH_BYTES = static_scratch_bytes(KK_SORT_STATIC_MAX_N);
 static __device__ __align__(256) unsigned char scratch[STATIC_SCRATCH_BYTES];

@@ -39,12 +39,9 @@
 #include "traverse.h"
 #include "wide_walk.h"
 
+#include "radix_hist.h"
+
 namespace kk {
-namespace rsort {
-int sort_pairs(uint32_t *keysA, uint32_t *keysB, uint32_t *valsA, uint32_t *valsB, bool iota,
-               uint32_t n, void *ws, size_t wsBytes, hipStream_t stream, uint32_t **errorFlagOut,
-               int passes);
-}
 extern "C" size_t kk_sort_workspace_bytes(uint32_t n);
 
 namespace accel {
@@ -619,23 +616,29 @@ __device__ __forceinline__ uint32_t spread3(uint32_t v) { // 10 bits -> every th
 // KEY_PASSES 8-bit passes
 constexpr int KEY_BITS = 5;
 constexpr int KEY_PASSES = (3 * KEY_BITS + 7) / 8;
+constexpr uint32_t KEYS_MAX_BLOCKS = 1024;
 __global__ __launch_bounds__(THREADS) void ray_keys_kernel(const Header *__restrict__ hdr,
                                                            const float *__restrict__ rays,
                                                            uint32_t rayNum,
-                                                           uint32_t *__restrict__ keys) {
-    const uint32_t r = blockIdx.x * THREADS + threadIdx.x;
-    if (r >= rayNum)
-        return;
-    const float *p = rays + 6ull * r;
-    uint32_t code = 0;
-    for (int a = 0; a < 3; ++a) {
-        const float lo = hdr->rootBox[a], hi = hdr->rootBox[3 + a];
-        const float ext = hi - lo;
-        float u = ext > 0.f ? (p[a] - lo) / ext : 0.f;
-        u = fminf(fmaxf(u * float(1 << KEY_BITS), 0.f), float((1 << KEY_BITS) - 1)); // NaN -> 0
-        code |= spread3(static_cast<uint32_t>(u)) << (2 - a);
+                                                           uint32_t *__restrict__ keys,
+                                                           uint32_t *__restrict__ ghist) {
+    // the digits of the keys are counted here for the sort that follows (radix_hist.h)
+    __shared__ uint32_t s_hist[KEY_PASSES * rsort::HIST_RADIX];
+    rsort::hist_clear<KEY_PASSES>(s_hist, threadIdx.x, THREADS);
+    for (uint32_t r = blockIdx.x * THREADS + threadIdx.x; r < rayNum; r += gridDim.x * THREADS) {
+        const float *p = rays + 6ull * r;
+        uint32_t code = 0;
+        for (int a = 0; a < 3; ++a) {
+            const float lo = hdr->rootBox[a], hi = hdr->rootBox[3 + a];
+            const float ext = hi - lo;
+            float u = ext > 0.f ? (p[a] - lo) / ext : 0.f;
+            u = fminf(fmaxf(u * float(1 << KEY_BITS), 0.f), float((1 << KEY_BITS) - 1)); // NaN -> 0
+            code |= spread3(static_cast<uint32_t>(u)) << (2 - a);
+        }
+        keys[r] = code;
+        rsort::hist_add<KEY_PASSES>(s_hist, code);
     }
-    keys[r] = code;
+    rsort::hist_flush<KEY_PASSES>(s_hist, ghist, threadIdx.x, THREADS);
 }
 
 // ---- traversal ------------------------------------------------------------------------------------
@@ -1090,10 +1093,17 @@ extern "C" int kk_closest_hit_accel(const void *d_accel, uint32_t face_num,
         auto *keysA = reinterpret_cast<uint32_t *>(b + w.keysA);
         auto *valsA = reinterpret_cast<uint32_t *>(b + w.valsA);
         auto *valsB = reinterpret_cast<uint32_t *>(b + w.valsB);
-        ray_keys_kernel<<<div_up(ray_num, THREADS), THREADS, 0, stream>>>(hdr, d_rays, ray_num, keysA);
+        uint32_t *ghist = nullptr;
+        int rc = rsort::sort_prepare(b + w.sortWs, w.sortWsBytes, ray_num, stream, &ghist);
+        if (rc != KK_OK)
+            return rc;
+        uint32_t kgrid = div_up(ray_num, THREADS);
+        if (kgrid > KEYS_MAX_BLOCKS)
+            kgrid = KEYS_MAX_BLOCKS;
+        ray_keys_kernel<<<kgrid, THREADS, 0, stream>>>(hdr, d_rays, ray_num, keysA, ghist);
         KK_LAUNCH_CHECK();
-        int rc = rsort::sort_pairs(keysA, reinterpret_cast<uint32_t *>(b + w.keysB), valsA, valsB, true,
-                                   ray_num, b + w.sortWs, w.sortWsBytes, stream, nullptr, KEY_PASSES);
+        rc = rsort::sort_pairs(keysA, reinterpret_cast<uint32_t *>(b + w.keysB), valsA, valsB, true, ray_num,
+                               b + w.sortWs, w.sortWsBytes, stream, nullptr, KEY_PASSES, true);
         if (rc != KK_OK)
             return rc;
         order = (KEY_PASSES & 1) ? valsB : valsA;
