@@ -298,8 +298,11 @@ int kk_pt_render_sample(const kk_lbvh_device_data *d_lbvh, const kk_pt_scene *h_
 
 /* Diagnostics of the path-tracing kernel on the trace-side tree: while d_counters (uint64[16], zeroed by
  * the caller) is set, every kk_pt_render_sample adds [0] passes of the waves' walk loop, [1] lanes that
- * walked in them, [2] shade phases, [3] lanes that waited at their start, [4] rays (closest-hit and
- * shadow), [5] node records visited, [6] triangles tested. NULL switches it off (the default). */
+ * walked in them, [2] runs of a shading section, [3] lanes they ran for, [4] rays (closest-hit and
+ * shadow), [5] node records visited, [6] triangles tested, [7] rounds of the pooled triangle test,
+ * [15] pairs tested in them, [14] triangles of the hit leaf slots alone, [8..13] clock cycles of one lane
+ * per wave in: walk loop control, record visits, triangle rounds, light samples, next directions, pixel
+ * write + refill. NULL switches it off (the default). */
 int kk_pt_set_work_counters(unsigned long long *d_counters);
 
 /* The other targets of RayTracer::Render (ray_tracer.h RenderTarget; ray_tracer_render.cu:461-558):

@@ -29,7 +29,7 @@ if __name__ == "__main__":
                           "tri_rounds_per_walk_pass": round(v[7] / max(v[0], 1), 2),
                           "pairs_per_tri_round": round(v[15] / max(v[7], 1), 1),
                           "walk_passes_per_shade": round(v[0] / max(v[2], 1), 1),
-                          "cycles_frac": {k: round(v[8 + i] / max(sum(v[8:15]), 1), 3) for i, k in
-                                          enumerate(("walk_loop", "visit", "tri", "lights", "bounce", "end", "coop"))},
+                          "cycles_frac": {k: round(v[8 + i] / max(sum(v[8:14]), 1), 3) for i, k in
+                                          enumerate(("walk_loop", "visit", "tri", "lights", "bounce", "end"))},
                           "cycles_per_walk_pass": round(v[9] / max(v[0], 1), 1),
                           "cycles_per_shade_section": round(sum(v[11:14]) / max(v[2], 1), 1)}))
