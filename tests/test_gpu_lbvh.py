@@ -228,10 +228,20 @@ def test_closest_hit_layouts_agree_bitwise():
     # squeeze a tenth of the triangles into one Morton cell so that long leaf runs exist
     pos = pos.copy().reshape(-1, 3, 3)
     pos[::10] = pos[::10] * np.float32(1e-4) + np.float32(0.5)
+    # ... and another tenth into 1500 cells of 1..39 triangles each: leaves that get a node of their own
+    # in the repacked tree (4..120 triangles), cut into chunks
+    sizes = 1 + (np.arange(1500) * 7919) % 39
+    cluster = np.searchsorted(np.cumsum(sizes), np.arange(30_000), side="right") % 1500
+    centre = syn.triangle_soup(1500, seed=5)[0].reshape(-1, 3, 3)[:, 0] * np.float32(0.9) + np.float32(0.05)
+    pos[1::10] = pos[1::10] * np.float32(1e-4) + centre[cluster][:, None, :]
     pos = pos.reshape(-1, 3)
     bvh = LBVH(DEV)
     bvh.BuildFrom(pos, tri)
     rays = syn.incoherent_rays(200_000)
+    # a tenth of the rays aimed at those cells
+    aim = centre[np.arange(20_000) % 1500] + np.float32(0.02)
+    d = aim - rays[100_000:120_000, :3]
+    rays[100_000:120_000, 3:] = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
     rays[:50_000, :3] = rays[:50_000, :3] * 3 - 1          # origins outside the unit box
     rays[1000:1300, 3:] = np.array([0, 0, -1], np.float32)  # axis-parallel
     rays[1300:1600, 3:] = np.array([0.6, 0, 0.8], np.float32)
@@ -242,6 +252,9 @@ def test_closest_hit_layouts_agree_bitwise():
         for a, b in zip(ref, got):
             assert a.tobytes() == b.tobytes()
     assert (ref[2] >= 0).mean() > 0.5
+    M = bvh.GetDeviceData()["compactedFaceNum"]
+    runs = np.diff(np.append(bvh.d_compacted[:M].cpu().numpy().view(np.uint32).astype(np.int64), tri.shape[0]))
+    assert ((runs >= 4) & (runs <= 120)).sum() > 500 and runs.max() > 10_000
 
 
 def test_closest_hit_veach_mis(oracle, veach):
