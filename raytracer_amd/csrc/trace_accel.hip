@@ -784,6 +784,22 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(5, 5)))
                     if (tEnter > tExit) { // misses the scene: retire at the next refill
                         active = false;
                         finished = true;
+                    } else {
+                        // Every ray's first record is the root: visited here, where its address is the
+                        // same for the whole wave and the record comes through the scalar cache instead
+                        // of five per-lane loads.
+                        bool anyNoLimit = false;
+                        const Visit vis = visit_record<false>(wideBytes, 0u, ray, sg, FloatMax, anyNoLimit);
+                        if (COUNT)
+                            ++nodeVisits;
+                        pendW = vis.leafW;
+                        pendC = vis.leafC;
+                        grpBase = vis.childBase;
+                        grpBits = octant_order(vis.inner, sg.oct) | (vis.imask << 8);
+                        if ((vis.inner | vis.leafC) == 0u) { // nothing of the root is hit
+                            active = false;
+                            finished = true;
+                        }
                     }
                 }
             }
