@@ -55,15 +55,27 @@ __global__ __launch_bounds__(THREADS) void bounds_partial_kernel(const float *__
     const int tid = threadIdx.x;
     float mn[3] = {FloatMax, FloatMax, FloatMax};
     float mx[3] = {FloatMin, FloatMin, FloatMin};
-    for (uint32_t v = blockIdx.x * THREADS + tid; v < vertNum; v += gridDim.x * THREADS) {
-        const float x = pos[3ull * v], y = pos[3ull * v + 1], z = pos[3ull * v + 2];
+    auto take = [&](float x, float y, float z) {
         mn[0] = gmin(mn[0], x);
         mn[1] = gmin(mn[1], y);
         mn[2] = gmin(mn[2], z);
         mx[0] = gmax(mx[0], x);
         mx[1] = gmax(mx[1], y);
         mx[2] = gmax(mx[2], z);
+    };
+    // four vertices = 48 contiguous bytes = three 16-byte loads per thread, when the array allows it
+    const bool aligned = (reinterpret_cast<uintptr_t>(pos) & 15u) == 0;
+    const uint32_t quads = aligned ? vertNum / 4 : 0;
+    const float4 *pos4 = reinterpret_cast<const float4 *>(pos);
+    for (uint32_t q = blockIdx.x * THREADS + tid; q < quads; q += gridDim.x * THREADS) {
+        const float4 a = pos4[3ull * q], b = pos4[3ull * q + 1], c = pos4[3ull * q + 2];
+        take(a.x, a.y, a.z);
+        take(a.w, b.x, b.y);
+        take(b.z, b.w, c.x);
+        take(c.y, c.z, c.w);
     }
+    for (uint32_t v = quads * 4 + blockIdx.x * THREADS + tid; v < vertNum; v += gridDim.x * THREADS)
+        take(pos[3ull * v], pos[3ull * v + 1], pos[3ull * v + 2]);
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         mn[k] = wave_min(mn[k]);
