@@ -390,7 +390,8 @@ enum : uint32_t {
 #define KK_PT_WAVES 4 // resident waves per SIMD = workgroups per CU
 #endif
 // A section of the shading code (light sample, next direction, pixel write + refill) runs for a wave when
-// at least this many of its lanes wait for it, or when no lane of the wave has a ray left to walk.
+// at least this many of its lanes wait for it (or as many as wait for the fullest of the three, if that
+// is fewer), or when no lane of the wave has a ray left to walk.
 // Measured on veach-mis 1080p: 1 -> 30.2 ms, 16 -> 26.2, 32 -> 24.8, 48 -> 28.3, 64 -> 30.9.
 constexpr int SECTION_MIN = 32;
 constexpr uint32_t COUNTER_SLOTS = 64;
@@ -620,11 +621,20 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(KK_PT_W
         // Each of the three sections below runs when enough lanes wait for it; lanes that are too few
         // wait through the next walk phase (other lanes of the wave still have rays to walk, or the
         // second turn of this loop takes everything that waits).
+        int sectionMin = SECTION_MIN;
+        {
+            const int nL0 = __popcll(__ballot(stage == ST_LIGHTS && ps.li < p.light_num));
+            const int nB0 = __popcll(__ballot(stage == ST_LIGHTS && ps.li >= p.light_num));
+            const int nE0 = __popcll(__ballot(stage == ST_END || (stage == ST_IDLE && !poolEmpty)));
+            const int big = nL0 > nB0 ? (nL0 > nE0 ? nL0 : nE0) : (nB0 > nE0 ? nB0 : nE0);
+            if (big < sectionMin)
+                sectionMin = big > 0 ? big : 1; // the fullest section always runs
+        }
         for (int force = 0; force < 2; ++force) {
         // light samples until the lane has a shadow ray out or is through its lights (:353-380)
         while (true) {
             const int nLights = __popcll(__ballot(stage == ST_LIGHTS && ps.li < p.light_num));
-            if (nLights == 0 || (!force && nLights < SECTION_MIN))
+            if (nLights == 0 || (!force && nLights < sectionMin))
                 break;
             if (COUNT) {
                 ++cntShades;
@@ -655,7 +665,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(KK_PT_W
         lap(tcLights);
         // after the last light: the path's next direction (:392-425)
         const int nBounce = __popcll(__ballot(stage == ST_LIGHTS && ps.li >= p.light_num));
-        if (nBounce != 0 && (force || nBounce >= SECTION_MIN)) {
+        if (nBounce != 0 && (force || nBounce >= sectionMin)) {
             if (COUNT) {
                 ++cntShades;
                 cntShadeLanes += nBounce;
@@ -696,7 +706,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(KK_PT_W
         // finished paths leave, new pixels come in
         const int nWaiting = __popcll(__ballot(stage == ST_END || stage == ST_IDLE));
         if ((__ballot(stage == ST_END) != 0ull || (nWaiting != 0 && !poolEmpty)) &&
-            (force || nWaiting >= SECTION_MIN)) {
+            (force || nWaiting >= sectionMin)) {
             if (COUNT) {
                 ++cntShades;
                 cntShadeLanes += __popcll(__ballot(stage == ST_END || stage == ST_IDLE));
