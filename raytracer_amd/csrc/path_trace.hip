@@ -387,7 +387,8 @@ enum : uint32_t {
 };
 
 #ifndef KK_PT_WAVES
-#define KK_PT_WAVES 4 // resident waves per SIMD = workgroups per CU
+#define KK_PT_WAVES 3 // resident waves per SIMD = workgroups per CU (168 registers, no spills; measured
+                      // on veach-mis 1080p: 3 -> 23.7 ms, 4 -> 24.0 (62 registers spilled), 5 -> 29.5, 6 -> 27.3)
 #endif
 // A section of the shading code (light sample, next direction, pixel write + refill) runs for a wave when
 // at least this many of its lanes wait for it (or as many as wait for the fullest of the three, if that
