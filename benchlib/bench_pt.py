@@ -27,22 +27,31 @@ def run(dev: str, size=(1920, 1080), spp: int = 16, frames: int = 5, with_cpu: b
     tracer, arr, c, proj = make_tracer(d, W, H, dev)
     fb = FrameBuffer(W, H, dev)
 
-    def frame():
+    def frame(batched=False):
         tracer.curr_accu_spp = 1.0  # restart the accumulation
-        for _ in range(spp):
-            tracer.Render(fb)
+        if batched:
+            tracer.Render(fb, samples=spp)
+        else:
+            for _ in range(spp):
+                tracer.Render(fb)
 
-    frame()
-    torch.cuda.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    ev0.record()
-    for _ in range(frames):
-        frame()
-    ev1.record()
-    torch.cuda.synchronize()
-    ms = ev0.elapsed_time(ev1) / frames
+    def timed(batched):
+        frame(batched)
+        torch.cuda.synchronize()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        for _ in range(frames):
+            frame(batched)
+        ev1.record()
+        torch.cuda.synchronize()
+        return ev0.elapsed_time(ev1) / frames
+
+    ms = timed(False)           # the reference's loop: one sample per Render call
+    ms_batched = timed(True)    # the same image from one call (Render(fb, samples=spp))
+    frame(False)
     out = {"workload": f"veach-mis {W}x{H}, {spp} spp, maxPathDepth 4",
            "ms_per_frame": round(ms, 3), "ms_per_sample_pass": round(ms / spp, 4),
+           "ms_per_frame_one_call": round(ms_batched, 3),
            "Mpaths_per_s": round(W * H * spp / (ms * 1e-3) / 1e6, 1)}
     if with_cpu:
         from oracle import kkoracle as ko

@@ -296,6 +296,16 @@ int kk_pt_render_sample(const kk_lbvh_device_data *d_lbvh, const kk_pt_scene *h_
                         const kk_pt_frame *h_frame, float *d_accum, uint8_t *d_rgba, int width,
                         int height, int y0, int y1, float sample_index, uint32_t seed, void *stream);
 
+/* sample_count consecutive calls of kk_pt_render_sample (sample_index, sample_index + 1, ...) as one
+ * launch: a lane renders the samples of its pixel one after the other, so the running mean of every
+ * pixel is folded in the same order and the result equals the separate calls bit for bit, while the
+ * GPU drains once per call instead of once per sample. The reference renders one sample per Render()
+ * (ray_tracer_render.cu:561-638); this is for callers that know they want several. */
+int kk_pt_render_samples(const kk_lbvh_device_data *d_lbvh, const kk_pt_scene *h_scene,
+                         const kk_pt_frame *h_frame, float *d_accum, uint8_t *d_rgba, int width,
+                         int height, int y0, int y1, float sample_index, int sample_count, uint32_t seed,
+                         void *stream);
+
 /* Diagnostics of the path-tracing kernel on the trace-side tree: while d_counters (uint64[16], zeroed by
  * the caller) is set, every kk_pt_render_sample adds [0] passes of the waves' walk loop, [1] lanes that
  * walked in them, [2] runs of a shading section, [3] lanes they ran for, [4] rays (closest-hit and

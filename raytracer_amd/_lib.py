@@ -114,6 +114,7 @@ def _declare(l):
     l.kk_closest_hit_accel_workspace_bytes.argtypes = [u32]
     l.kk_closest_hit_accel.argtypes = [vp, u32, u32, vp, u32, vp, vp, vp, u32, vp, vp, sz, vp]
     l.kk_pt_render_sample.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, C.c_float, u32, vp]
+    l.kk_pt_render_samples.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, C.c_float, i32, u32, vp]
     l.kk_rt_render_target.argtypes = [vp, vp, vp, i32, vp, i32, i32, i32, i32, vp]
     l.kk_rng_uniforms.argtypes = [u32, u32, u32, u32, vp, vp]
     for sfx in ("u8", "u16"):

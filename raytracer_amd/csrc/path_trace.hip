@@ -383,7 +383,8 @@ enum : uint32_t {
     ST_LIGHTS = 6, // choosing the next light that needs a shadow ray, or the path's next direction
     ST_END = 7,    // path over: pixel to be written
     ST_LAUNCH_C = 8, // a closest-hit ray (ray.pos, ray.dir) waits to be set up ...
-    ST_LAUNCH_S = 9  // ... a shadow ray that ends at rayFar
+    ST_LAUNCH_S = 9, // ... a shadow ray that ends at rayFar
+    ST_NEXT_SAMPLE = 10 // has a pixel, the camera ray of its next sample is to be made
 };
 
 #ifndef KK_PT_WAVES
@@ -404,6 +405,7 @@ static __device__ uint32_t g_pixelQueue[COUNTER_SLOTS * 32];
 struct PathState {
     // the path
     uint32_t pixel;  // y * W + x
+    uint32_t sample; // which sample of the pixel this path is (1-based)
     uint32_t draw;   // random numbers drawn so far
     uint32_t depth;  // bounce
     uint32_t li;     // light being sampled
@@ -417,7 +419,7 @@ struct PathState {
 template <bool COUNT>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(KK_PT_WAVES, KK_PT_WAVES))) void path_trace_persistent_kernel(
     const accel::View view, const kk_pt_scene p, const kk_pt_frame f, float *__restrict__ accum,
-    uint8_t *__restrict__ rgba, int W, int H, int y0, int y1, float sampleIdx, uint32_t seed,
+    uint8_t *__restrict__ rgba, int W, int H, int y0, int y1, float sampleIdx, int sampleCount, uint32_t seed,
     uint32_t *pixelQueue, unsigned long long *counters) {
     using namespace persist;
     using namespace accel;
@@ -441,7 +443,10 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(KK_PT_W
     const uint32_t tilesX = (static_cast<uint32_t>(W) + 7u) >> 3;
     const uint32_t tilesY = (static_cast<uint32_t>(y1 - y0) + 7u) >> 3;
     const uint32_t queueLen = tilesX * tilesY * 64u;
-    const uint32_t sample = static_cast<uint32_t>(sampleIdx);
+    // a lane renders samples sampleFirst .. sampleFirst + sampleCount - 1 of its pixel one after the other
+    // (the running mean of a pixel is order dependent) before it takes another pixel
+    const uint32_t sampleFirst = static_cast<uint32_t>(sampleIdx);
+    const uint32_t sampleEnd = sampleFirst + static_cast<uint32_t>(sampleCount);
     constexpr float RR = .8f;
 
     uint32_t stage = ST_IDLE;
@@ -642,7 +647,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(KK_PT_W
                 cntShadeLanes += nLights;
             }
             if (stage == ST_LIGHTS && ps.li < p.light_num) {
-                Rng rng{seed, ps.pixel, sample, ps.draw};
+                Rng rng{seed, ps.pixel, ps.sample, ps.draw};
                 const kk_light lht = p.lights[ps.li];
                 float u0, u1, unused2, unused3;
                 rng.next4(u0, u1, unused2, unused3);
@@ -673,7 +678,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(KK_PT_W
             }
             if (stage == ST_LIGHTS && ps.li >= p.light_num) {
                 const kk_material matr = p.materials[ps.grp];
-                Rng rng{seed, ps.pixel, sample, ps.draw};
+                Rng rng{seed, ps.pixel, ps.sample, ps.draw};
                 float pdfIndrct;
                 float u, u0, u1, uRoulette;
                 rng.next4(u, u0, u1, uRoulette);
@@ -720,7 +725,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(KK_PT_W
                 Lo.z = powf(Lo.z, 1.f / 2.2f);
                 const uint32_t idx = ps.pixel;
                 const f3 prev = {accum[3ull * idx], accum[3ull * idx + 1], accum[3ull * idx + 2]};
-                const f3 color = prev + (Lo - prev) / sampleIdx;
+                const f3 color = prev + (Lo - prev) / static_cast<float>(ps.sample);
                 accum[3ull * idx] = color.x;
                 accum[3ull * idx + 1] = color.y;
                 accum[3ull * idx + 2] = color.z;
@@ -730,7 +735,8 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(KK_PT_W
                 o.z = static_cast<uint8_t>(255.f * color.z);
                 o.w = 255;
                 reinterpret_cast<uchar4 *>(rgba)[idx] = o;
-                stage = ST_IDLE;
+                ++ps.sample;
+                stage = ps.sample < sampleEnd ? ST_NEXT_SAMPLE : ST_IDLE;
             }
             // idle lanes take the next pixels of the queue (:592-619)
             const unsigned long long idleMask = __ballot(stage == ST_IDLE);
@@ -752,47 +758,54 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(KK_PT_W
                         const int y = y0 + static_cast<int>(ty * 8u + (in >> 3));
                         if (x < W && y < y1) {
                             ps.pixel = static_cast<uint32_t>(y) * W + x;
-                            Rng rng{seed, ps.pixel, sample, 0};
-                            m4 invProj, w2s;
-                            m3 rot;
-                            for (int c = 0; c < 4; ++c) {
-                                invProj.c[c] = {p.inv_proj[4 * c], p.inv_proj[4 * c + 1], p.inv_proj[4 * c + 2],
-                                                p.inv_proj[4 * c + 3]};
-                                w2s.c[c] = {p.w2s[4 * c], p.w2s[4 * c + 1], p.w2s[4 * c + 2], p.w2s[4 * c + 3]};
-                            }
-                            for (int c = 0; c < 3; ++c)
-                                rot.c[c] = {f.eye_rot[3 * c], f.eye_rot[3 * c + 1], f.eye_rot[3 * c + 2]};
-                            f4 tmp;
-                            float jx, jy, unused2, unused3;
-                            rng.next4(jx, jy, unused2, unused3);
-                            tmp.x = 1.f - jx + x;
-                            tmp.y = 1.f - jy + y;
-                            tmp.z = static_cast<float>(W);
-                            tmp.w = static_cast<float>(H);
-                            tmp.x = (2.f * tmp.x - tmp.z) / tmp.z;
-                            tmp.y = (2.f * tmp.y - tmp.w) / tmp.w;
-                            tmp.z = 1.f;
-                            tmp.w = 1.f;
-                            tmp = invProj * tmp;
-                            f3 dir = {tmp.x, tmp.y, tmp.z};
-                            dir = rot * normalize(dir);
-                            // the reference transforms a temporary by w2s and discards it (:612-614)
-                            dir = normalize(dir);
-                            const f4 pp = w2s * f4{f.eye_pos[0], f.eye_pos[1], f.eye_pos[2], 1.f};
-                            ps.draw = rng.draw;
-                            ps.depth = 0u;
-                            ps.throughout = F3(1.f);
-                            ps.Lo = F3(0.f);
-                            // renderScene's loop test before the first bounce (:318-320)
-                            if (p.max_path_depth > 0) {
-                                ray.pos = F3(pp.x, pp.y, pp.z);
-                                ray.dir = dir;
-                                stage = ST_LAUNCH_C;
-                            } else
-                                stage = ST_END;
+                            ps.sample = sampleFirst;
+                            stage = ST_NEXT_SAMPLE;
                         }
                     }
                 }
+            }
+            // the camera ray of a pixel's next sample (:592-619)
+            if (stage == ST_NEXT_SAMPLE) {
+                const int x = static_cast<int>(ps.pixel % static_cast<uint32_t>(W));
+                const int y = static_cast<int>(ps.pixel / static_cast<uint32_t>(W));
+                Rng rng{seed, ps.pixel, ps.sample, 0};
+                m4 invProj, w2s;
+                m3 rot;
+                for (int c = 0; c < 4; ++c) {
+                    invProj.c[c] = {p.inv_proj[4 * c], p.inv_proj[4 * c + 1], p.inv_proj[4 * c + 2],
+                                    p.inv_proj[4 * c + 3]};
+                    w2s.c[c] = {p.w2s[4 * c], p.w2s[4 * c + 1], p.w2s[4 * c + 2], p.w2s[4 * c + 3]};
+                }
+                for (int c = 0; c < 3; ++c)
+                    rot.c[c] = {f.eye_rot[3 * c], f.eye_rot[3 * c + 1], f.eye_rot[3 * c + 2]};
+                f4 tmp;
+                float jx, jy, unused2, unused3;
+                rng.next4(jx, jy, unused2, unused3);
+                tmp.x = 1.f - jx + x;
+                tmp.y = 1.f - jy + y;
+                tmp.z = static_cast<float>(W);
+                tmp.w = static_cast<float>(H);
+                tmp.x = (2.f * tmp.x - tmp.z) / tmp.z;
+                tmp.y = (2.f * tmp.y - tmp.w) / tmp.w;
+                tmp.z = 1.f;
+                tmp.w = 1.f;
+                tmp = invProj * tmp;
+                f3 dir = {tmp.x, tmp.y, tmp.z};
+                dir = rot * normalize(dir);
+                // the reference transforms a temporary by w2s and discards it (:612-614)
+                dir = normalize(dir);
+                const f4 pp = w2s * f4{f.eye_pos[0], f.eye_pos[1], f.eye_pos[2], 1.f};
+                ps.draw = rng.draw;
+                ps.depth = 0u;
+                ps.throughout = F3(1.f);
+                ps.Lo = F3(0.f);
+                // renderScene's loop test before the first bounce (:318-320)
+                if (p.max_path_depth > 0) {
+                    ray.pos = F3(pp.x, pp.y, pp.z);
+                    ray.dir = dir;
+                    stage = ST_LAUNCH_C;
+                } else
+                    stage = ST_END;
             }
         }
         if (__ballot(stage == ST_LAUNCH_C || stage == ST_LAUNCH_S || stage == ST_WALK_C || stage == ST_WALK_S) != 0ull)
@@ -872,15 +885,17 @@ static int persist_queue_ptr(uint32_t **out) {
 } // namespace pt
 } // namespace kk
 
-extern "C" int kk_pt_render_sample(const kk_lbvh_device_data *d_lbvh, const kk_pt_scene *h_scene,
-                                   const kk_pt_frame *h_frame, float *d_accum, uint8_t *d_rgba,
-                                   int width, int height, int y0, int y1, float sample_index,
-                                   uint32_t seed, void *stream_) {
+extern "C" int kk_pt_render_samples(const kk_lbvh_device_data *d_lbvh, const kk_pt_scene *h_scene,
+                                    const kk_pt_frame *h_frame, float *d_accum, uint8_t *d_rgba,
+                                    int width, int height, int y0, int y1, float sample_index,
+                                    int sample_count, uint32_t seed, void *stream_) {
     using namespace kk;
     using namespace kk::pt;
     KK_REQUIRE(d_lbvh && h_scene && h_frame && d_accum && d_rgba, "null pointer");
     KK_REQUIRE(width > 0 && height > 0 && y0 >= 0 && y1 <= height && y0 <= y1, "bad image size or rows");
     KK_REQUIRE(sample_index >= 1.f, "sample_index is 1-based");
+    KK_REQUIRE(sample_count >= 1 && sample_count <= 65536 && sample_index < 16777216.f - 65536.f,
+               "sample_count out of range");
     KK_REQUIRE(h_scene->triangles && h_scene->tri_to_position_indices && h_scene->positions &&
                    h_scene->normals && h_scene->materials,
                "scene arrays missing");
@@ -912,17 +927,29 @@ extern "C" int kk_pt_render_sample(const kk_lbvh_device_data *d_lbvh, const kk_p
         unsigned long long *dbg = g_debugCounters.load();
         if (dbg)
             path_trace_persistent_kernel<true><<<pgrid, THREADS, 0, stream>>>(
-                view, *h_scene, *h_frame, d_accum, d_rgba, width, height, y0, y1, sample_index, seed, head, dbg);
+                view, *h_scene, *h_frame, d_accum, d_rgba, width, height, y0, y1, sample_index, sample_count, seed,
+                head, dbg);
         else
             path_trace_persistent_kernel<false><<<pgrid, THREADS, 0, stream>>>(
-                view, *h_scene, *h_frame, d_accum, d_rgba, width, height, y0, y1, sample_index, seed, head,
-                nullptr);
+                view, *h_scene, *h_frame, d_accum, d_rgba, width, height, y0, y1, sample_index, sample_count, seed,
+                head, nullptr);
     } else
-        path_trace_kernel<false><<<grid, THREADS, 0, static_cast<hipStream_t>(stream_)>>>(
-            d_lbvh, accel::View{}, *h_scene, *h_frame, d_accum, d_rgba, width, height, y0, y1, sample_index,
-            seed);
+        for (int s = 0; s < sample_count; ++s) { // a launch per sample, in order
+            path_trace_kernel<false><<<grid, THREADS, 0, static_cast<hipStream_t>(stream_)>>>(
+                d_lbvh, accel::View{}, *h_scene, *h_frame, d_accum, d_rgba, width, height, y0, y1,
+                sample_index + static_cast<float>(s), seed);
+            KK_LAUNCH_CHECK();
+        }
     KK_LAUNCH_CHECK();
     return KK_OK;
+}
+
+extern "C" int kk_pt_render_sample(const kk_lbvh_device_data *d_lbvh, const kk_pt_scene *h_scene,
+                                   const kk_pt_frame *h_frame, float *d_accum, uint8_t *d_rgba,
+                                   int width, int height, int y0, int y1, float sample_index,
+                                   uint32_t seed, void *stream_) {
+    return kk_pt_render_samples(d_lbvh, h_scene, h_frame, d_accum, d_rgba, width, height, y0, y1,
+                                sample_index, 1, seed, stream_);
 }
 
 extern "C" int kk_pt_set_work_counters(unsigned long long *d_counters) {

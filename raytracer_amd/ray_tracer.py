@@ -270,11 +270,12 @@ class RayTracer:
     RENDER_TARGETS = ("Scene", "AABBs", "Triangles", "Lights", "Positions", "Normals", "TextureCoords",
                       "None")
 
-    def Render(self, fb: FrameBuffer, rows=None, target: str = "Scene") -> None:
+    def Render(self, fb: FrameBuffer, rows=None, target: str = "Scene", samples: int = 1) -> None:
         """ray_tracer_render.cu:433-647. `target` is one of RENDER_TARGETS (RayTracer::RenderTarget);
         "Scene" path-traces and accumulates one sample, the others draw one inspection frame. `rows` =
         (y0, y1) restricts the call to a stripe of the image (multi-GPU tiling); the sample counter
-        advances all the same."""
+        advances all the same. `samples` > 1 does the work of that many consecutive calls in one launch
+        (same image, bit for bit; never past maxSamplePerPixel)."""
         import sys
         if self.lbvh is None or not self.lbvh.IsComplete():
             print(f"{self.ErrTag} lbvh is not set.", file=sys.stderr)
@@ -313,10 +314,11 @@ class RayTracer:
                 self._scene.accel_face_num, self._scene.accel_compacted_face_num = self.lbvh._accel_sizes
             else:
                 self._scene.trace_accel = None
-            _lib.check(_lib.lib().kk_pt_render_sample(
+            n = int(min(max(int(samples), 1), self.max_sample_per_pixel - self.curr_accu_spp + 1))
+            _lib.check(_lib.lib().kk_pt_render_samples(
                 self.lbvh.GetDeivceDataDevicePtr(), C.byref(self._scene), C.byref(self._frame),
                 self.d_accum.data_ptr(), fb.rgba.data_ptr(), fb.width, fb.height, int(y0), int(y1),
-                C.c_float(self.curr_accu_spp), self.SEED, _lib.current_stream_ptr()),
-                "kk_pt_render_sample")
+                C.c_float(self.curr_accu_spp), n, self.SEED, _lib.current_stream_ptr()),
+                "kk_pt_render_samples")
         self._prev_max_spp = self.max_sample_per_pixel
-        self.curr_accu_spp += 1.0
+        self.curr_accu_spp += float(n)

@@ -214,3 +214,37 @@ def test_quad_light_and_long_leaves(oracle):
     assert float(np.abs(got - ref).mean()) < 1e-4
     lit = got.max(axis=2) > 0.02
     assert 0.5 < float(lit.mean()) <= 1.0
+
+
+def test_several_samples_in_one_launch_equal_separate_calls(veach):
+    """Render(fb, samples=n) = n calls of Render(fb): every pixel folds its samples into the running mean
+    in the same order, so the accumulation buffer and the surface are equal bit for bit; the counter
+    stops at maxSamplePerPixel."""
+    W, H = 192, 108
+    tracer, *_ = _setup(veach, W, H)
+    fb = FrameBuffer(W, H, DEV)
+    for _ in range(5):
+        tracer.Render(fb)
+    torch.cuda.synchronize()
+    one_by_one = (tracer.d_accum.cpu().numpy().tobytes(), fb.ReadBack().tobytes())
+    tracer2, *_ = _setup(veach, W, H)
+    fb2 = FrameBuffer(W, H, DEV)
+    tracer2.Render(fb2, samples=2)
+    tracer2.Render(fb2, samples=3)
+    torch.cuda.synchronize()
+    assert tracer2.GetCurrentAccumulatedSamplePerPixel() == 6
+    assert (tracer2.d_accum.cpu().numpy().tobytes(), fb2.ReadBack().tobytes()) == one_by_one
+    # the binary-tree path takes the same call
+    tracer3, *_ = _setup(veach, W, H)
+    tracer3.use_trace_tree = False
+    fb3 = FrameBuffer(W, H, DEV)
+    tracer3.Render(fb3, samples=5)
+    torch.cuda.synchronize()
+    assert (tracer3.d_accum.cpu().numpy().tobytes(), fb3.ReadBack().tobytes()) == one_by_one
+    # never past the cap: two more samples fit under a cap of 7, a third call does nothing
+    tracer2.max_sample_per_pixel = 7.0
+    tracer2._prev_max_spp = 7.0
+    tracer2.Render(fb2, samples=10)
+    assert tracer2.GetCurrentAccumulatedSamplePerPixel() == 8
+    tracer2.Render(fb2, samples=10)
+    assert tracer2.GetCurrentAccumulatedSamplePerPixel() == 8
