@@ -156,7 +156,10 @@ class RayTracer : Noncopyable {
     // One call adds one sample per pixel; accumulation restarts when a parameter, the size, the target
     // or the framebuffer changed, and the call is a no-op once the sample budget is used up
     // (ray_tracer_render.cu:561-577, 640-641).
-    void Render(HIP::FrameBuffer &rndrTo, const ivec2 &rndrSz, RenderTarget rndrTarget = RenderTarget::Scene) {
+    // `samples` > 1 (not in the reference) does the work of that many consecutive calls in one launch: the
+    // same image bit for bit, never past the sample budget.
+    void Render(HIP::FrameBuffer &rndrTo, const ivec2 &rndrSz, RenderTarget rndrTarget = RenderTarget::Scene,
+                int samples = 1) {
         if (!lbvh || !lbvh->IsComplete()) {
             std::cerr << ErrTag << " at " << __FILE__ << ":" << __LINE__ << ". lbvh is not set.\n";
             return;
@@ -199,15 +202,19 @@ class RayTracer : Noncopyable {
         prevRndrTarget = rndrTarget;
         if (currAccuSamplePerPixel > maxSamplePerPixel)
             return;
+        int n = samples < 1 ? 1 : samples;
+        const float left = maxSamplePerPixel - currAccuSamplePerPixel + 1.f;
+        if (static_cast<float>(n) > left)
+            n = static_cast<int>(left);
         if (!KOUEK_HIP_CHECK(ErrTag.data(),
-                             kk_pt_render_sample(reinterpret_cast<const kk_lbvh_device_data *>(
-                                                     lbvh->GetDeivceDataDevicePtr()),
-                                                 &scene, &frame, reinterpret_cast<float *>(d_accuRndrTo.data()),
-                                                 rndrTo.Get(), rndrSz.x, rndrSz.y, 0, rndrSz.y,
-                                                 currAccuSamplePerPixel, Seed, nullptr)))
+                             kk_pt_render_samples(reinterpret_cast<const kk_lbvh_device_data *>(
+                                                      lbvh->GetDeivceDataDevicePtr()),
+                                                  &scene, &frame, reinterpret_cast<float *>(d_accuRndrTo.data()),
+                                                  rndrTo.Get(), rndrSz.x, rndrSz.y, 0, rndrSz.y,
+                                                  currAccuSamplePerPixel, n, Seed, nullptr)))
             return;
         prevMaxSamplePerPixel = maxSamplePerPixel;
-        currAccuSamplePerPixel += 1.f;
+        currAccuSamplePerPixel += static_cast<float>(n);
     }
 
     std::vector<vec3> ReadAccumulation() const { return d_accuRndrTo.to_host(); }
