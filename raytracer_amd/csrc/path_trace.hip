@@ -387,10 +387,12 @@ enum : uint32_t {
     ST_NEXT_SAMPLE = 10 // has a pixel, the camera ray of its next sample is to be made
 };
 
-#ifndef KK_PT_WAVES
-#define KK_PT_WAVES 3 // resident waves per SIMD = workgroups per CU (168 registers, no spills; measured
-                      // on veach-mis 1080p: 3 -> 23.7 ms, 4 -> 24.0 (62 registers spilled), 5 -> 29.5, 6 -> 27.3)
-#endif
+// Resident waves per SIMD = workgroups per CU, a compile-time choice of the kernel. Measured on veach-mis
+// 1080p: a launch of one sample pass (1.5 ms) is fastest with 3 (168 registers, nothing spilled: 23.7 ms
+// per 16 passes; 4 -> 24.1, 5 -> 29.5, 6 -> 27.3), a launch of 16 samples per pixel with 4 (21.5 ms
+// against 22.3): the long launch gains more from the fourth wave than it loses to 62 spilled registers.
+constexpr int WAVES_SHORT = 3, WAVES_LONG = 4;
+constexpr int LONG_LAUNCH_SAMPLES = 4; // from this many samples per pixel on a launch counts as long
 // A section of the shading code (light sample, next direction, pixel write + refill) runs for a wave when
 // at least this many of its lanes wait for it (or as many as wait for the fullest of the three, if that
 // is fewer), or when no lane of the wave has a ray left to walk.
@@ -416,8 +418,8 @@ struct PathState {
 
 } // namespace persist
 
-template <bool COUNT>
-__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(KK_PT_WAVES, KK_PT_WAVES))) void path_trace_persistent_kernel(
+template <bool COUNT, int WAVES>
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void path_trace_persistent_kernel(
     const accel::View view, const kk_pt_scene p, const kk_pt_frame f, float *__restrict__ accum,
     uint8_t *__restrict__ rgba, int W, int H, int y0, int y1, float sampleIdx, int sampleCount, uint32_t seed,
     uint32_t *pixelQueue, unsigned long long *counters) {
@@ -921,18 +923,28 @@ extern "C" int kk_pt_render_samples(const kk_lbvh_device_data *d_lbvh, const kk_
         KK_HIP_TRY(hipMemsetAsync(head, 0, sizeof(uint32_t), stream));
         const uint32_t queueLen = div_up(width, 8) * div_up(y1 - y0, 8) * 64u;
         uint32_t pgrid = div_up(queueLen, THREADS);
-        const uint32_t resident = KK_PT_WAVES * static_cast<uint32_t>(device_cu_count());
+        const bool longLaunch = sample_count >= persist::LONG_LAUNCH_SAMPLES;
+        const uint32_t resident = static_cast<uint32_t>(longLaunch ? persist::WAVES_LONG : persist::WAVES_SHORT) *
+                                  static_cast<uint32_t>(device_cu_count());
         if (pgrid > resident)
             pgrid = resident;
         unsigned long long *dbg = g_debugCounters.load();
-        if (dbg)
-            path_trace_persistent_kernel<true><<<pgrid, THREADS, 0, stream>>>(
-                view, *h_scene, *h_frame, d_accum, d_rgba, width, height, y0, y1, sample_index, sample_count, seed,
-                head, dbg);
-        else
-            path_trace_persistent_kernel<false><<<pgrid, THREADS, 0, stream>>>(
-                view, *h_scene, *h_frame, d_accum, d_rgba, width, height, y0, y1, sample_index, sample_count, seed,
-                head, nullptr);
+#define KK_LAUNCH_PT(COUNT, WAVES)                                                                    \
+    path_trace_persistent_kernel<COUNT, WAVES><<<pgrid, THREADS, 0, stream>>>(                           \
+        view, *h_scene, *h_frame, d_accum, d_rgba, width, height, y0, y1, sample_index, sample_count, seed, \
+        head, dbg)
+        if (dbg) {
+            if (longLaunch)
+                KK_LAUNCH_PT(true, persist::WAVES_LONG);
+            else
+                KK_LAUNCH_PT(true, persist::WAVES_SHORT);
+        } else {
+            if (longLaunch)
+                KK_LAUNCH_PT(false, persist::WAVES_LONG);
+            else
+                KK_LAUNCH_PT(false, persist::WAVES_SHORT);
+        }
+#undef KK_LAUNCH_PT
     } else
         for (int s = 0; s < sample_count; ++s) { // a launch per sample, in order
             path_trace_kernel<false><<<grid, THREADS, 0, static_cast<hipStream_t>(stream_)>>>(

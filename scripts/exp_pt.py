@@ -19,7 +19,7 @@ if __name__ == "__main__":
         torch.cuda.synchronize()
         _lib.lib().kk_pt_set_work_counters(None)
         v = [int(x) for x in c.cpu()]
-        spp = 32  # warm-up frame + one timed frame of 16 passes
+        spp = 80  # bench_pt.run renders five frames of 16 samples: two per timing form and a last one
         print(json.dumps({"walk_passes_per_wave_sum": v[0], "lanes_per_walk_pass": round(v[1] / max(v[0], 1), 1),
                           "shade_phases": v[2], "lanes_per_shade": round(v[3] / max(v[2], 1), 1),
                           "rays_per_path": round(v[4] / (1920 * 1080 * spp), 2),
