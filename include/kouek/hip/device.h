@@ -103,6 +103,19 @@ struct uchar4 {
     uint8_t x, y, z, w;
 };
 
+// A HIP stream of the application's own (not in the reference, whose calls all go to the default stream).
+// The render calls take one optionally: frames rendered alternately on two streams into two frame buffers
+// overlap, which hides the end of each frame, where only its longest rays are still marching.
+class Stream : Noncopyable {
+    void *s = nullptr;
+
+  public:
+    Stream() { kk_stream_create(&s); }
+    ~Stream() { kk_stream_destroy(s); }
+    void *Get() const { return s; }
+    void Synchronize() const { kk_stream_synchronize(s); }
+};
+
 // Stands in for the cudaSurfaceObject_t of the reference's Render calls: RGBA8, row 0 = bottom row,
 // pitch = 4 * width.
 class FrameBuffer : Noncopyable {

@@ -93,7 +93,8 @@ class RayCaster : Noncopyable {
     enum class DPBXVDBRenderTarget { Scene, AABBs, Depths, PositionsAfterDepthSkip };
     template <typename T>
     void RenderDepthBoxVDB(HIP::FrameBuffer &rndrTo, const ivec2 &rndrSz,
-                           DPBXVDBRenderTarget rndrTarget = DPBXVDBRenderTarget::Scene) {
+                           DPBXVDBRenderTarget rndrTarget = DPBXVDBRenderTarget::Scene,
+                           const HIP::Stream *stream = nullptr) {
         if (!vdb || !tfTex || !vdb->IsComplete()) {
             std::cerr << ErrTag << " at " << __FILE__ << ":" << __LINE__ << ". vdb or tfTex are not set.\n";
             return;
@@ -102,7 +103,7 @@ class RayCaster : Noncopyable {
         KOUEK_HIP_CHECK(ErrTag.data(),
                         fn(&vdb->GetDeviceData(), tfTex->Get(), &rndrParam, &rndrParamPerFrame,
                            static_cast<int>(rndrTarget), displayLev, displayLeafLayer, rndrTo.Get(), rndrSz.x,
-                           rndrSz.y, 0, rndrSz.y, nullptr));
+                           rndrSz.y, 0, rndrSz.y, stream ? stream->Get() : nullptr));
     }
 
     // Several GPUs (not part of the reference): every rank of `comm` renders its round-robin 16-row

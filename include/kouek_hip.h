@@ -47,6 +47,10 @@ int kk_memcpy_h2d(void *d_dst, const void *h_src, size_t bytes, void *stream);
 int kk_memcpy_d2h(void *h_dst, const void *d_src, size_t bytes, void *stream);
 int kk_memset(void *d_dst, int value, size_t bytes, void *stream);
 int kk_stream_synchronize(void *stream);
+/* A HIP stream of the caller's own (hipStreamNonBlocking), for work that should overlap: two frames in
+ * flight on two streams render half as fast again as one after the other (see INTEGRATION). */
+int kk_stream_create(void **out_stream);
+int kk_stream_destroy(void *stream);
 
 /* ================================================================================================
  * Path 1a: LBVH build  --  kouek::RayTracer::LBVH::BuildFrom (src/ray_tracer/lbvh.cu:100-323)

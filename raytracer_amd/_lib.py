@@ -117,6 +117,8 @@ def _declare(l):
     l.kk_pt_render_samples.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, C.c_float, i32, u32, vp]
     l.kk_rt_render_target.argtypes = [vp, vp, vp, i32, vp, i32, i32, i32, i32, vp]
     l.kk_rng_uniforms.argtypes = [u32, u32, u32, u32, vp, vp]
+    l.kk_stream_create.argtypes = [C.POINTER(vp)]
+    l.kk_stream_destroy.argtypes = [vp]
     for sfx in ("u8", "u16"):
         getattr(l, f"kk_vdb_classify_{sfx}").argtypes = [vp, u32, u32, u32, u32, vp, u32, vp, vp]
         getattr(l, f"kk_vdb_fill_atlas_{sfx}").argtypes = [vp, u32, u32, u32, vp, vp, vp, u32, vp, vp]

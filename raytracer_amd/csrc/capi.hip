@@ -66,3 +66,15 @@ extern "C" int kk_stream_synchronize(void *stream) {
     KK_HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
     return KK_OK;
 }
+extern "C" int kk_stream_create(void **out_stream) {
+    KK_REQUIRE(out_stream != nullptr, "null pointer");
+    hipStream_t s = nullptr;
+    KK_HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *out_stream = s;
+    return KK_OK;
+}
+extern "C" int kk_stream_destroy(void *stream) {
+    if (stream)
+        KK_HIP_TRY(hipStreamDestroy(static_cast<hipStream_t>(stream)));
+    return KK_OK;
+}

@@ -143,6 +143,14 @@ int main(int argc, char **argv) {
     kk_stream_synchronize(nullptr);
     dfb.ReadBack(img);
     save(out + "/dvr_rgba.u8", img);
+    { // the same frame on a stream of the application's own (what two frames in flight use)
+        HIP::Stream own;
+        HIP::FrameBuffer dfb2(dsz);
+        caster.RenderDepthBoxVDB<uint8_t>(dfb2, dsz, RayCaster::RayCaster::DPBXVDBRenderTarget::Scene, &own);
+        own.Synchronize();
+        dfb2.ReadBack(img);
+        save(out + "/dvr_rgba_own_stream.u8", img);
+    }
     // the several-GPU calls with a one-rank communicator: both structures broadcast (each a single
     // allocation), the frame rendered as compact stripes, gathered and put back in image order
     {

@@ -172,6 +172,36 @@ def test_row_split_gives_the_same_frame(oracle):
     assert fb2.ReadBack().tobytes() == got.tobytes()
 
 
+def test_frames_in_flight_on_two_streams_equal_serial_frames(oracle):
+    """Camera parameters travel by value with each launch, so a frame queued on one stream is not
+    disturbed by the setters called for the next frame while it is still running."""
+    dim = (64, 128, 128)
+    vol = syn.head_volume(dim)
+    vdb, ref = _build_both(oracle, vol, (4, 3, 3), HEAD_TF.empty_scalar_ranges)
+    W, H = 320, 240
+    _, _, _, _, caster, fb = _render_both(oracle, vdb, ref, HEAD_TF, dim, (2, 1, 1), W, H)
+    poses = []
+    for orbit in (0, 35, 70, 105, 140, 175):
+        _, c, _ = dvr_setup(dim, (2, 1, 1), W, H, 1.0, orbit)
+        poses.append((c.pos, c.rotation()))
+    serial = []
+    for pose in poses:
+        caster.SetCameraToWorld(*pose)
+        caster.RenderDepthBoxVDB(fb)
+        torch.cuda.synchronize()
+        serial.append(fb.ReadBack().copy())
+    assert serial[0].tobytes() != serial[3].tobytes()
+    streams = [torch.cuda.Stream(DEV), torch.cuda.Stream(DEV)]
+    fbs = [FrameBuffer(W, H, DEV) for _ in poses]
+    for i, pose in enumerate(poses):
+        caster.SetCameraToWorld(*pose)
+        with torch.cuda.stream(streams[i & 1]):
+            caster.RenderDepthBoxVDB(fbs[i])
+    torch.cuda.synchronize()
+    for i in range(len(poses)):
+        assert fbs[i].ReadBack().tobytes() == serial[i].tobytes(), f"frame {i}"
+
+
 def test_render_without_vdb_reports_and_returns(capsys):
     RayCaster(DEV).RenderDepthBoxVDB(FrameBuffer(8, 8, DEV))
     assert "vdb or tfTex are not set" in capsys.readouterr().err
