@@ -6,8 +6,8 @@
 //   morton                      : 30-bit code of each triangle's box centre    (lbvh.cu:136-170)
 //   radix sort (radix_sort.hip) : stable sort of (code, face)                  (lbvh.cu:110,172)
 //   count_heads/scan/compact    : run starts of equal codes -> leaves          (algorithm.h:11-41)
-//   leaf_aabb                   : one box per run                              (lbvh.cu:186-219)
 //   karras_links                : children of each internal node (+ parents)   (lbvh.cu:29-98,221-260)
+//                                 and, in the same threads, one box per run      (lbvh.cu:186-219)
 //   refit_window/block_totals/  : node boxes as in-order folds over each node's leaf range (no
 //   refit_span                    arrival counters). The reference walks each node's whole subtree
 //                                 (lbvh.cu:265-297); min/max unions are exact, so both give the same bits.
@@ -322,85 +322,62 @@ __global__ __launch_bounds__(THREADS) void compact_heads_kernel(
         }
 }
 
-// lbvh.cu:186-219, one thread per leaf (run of equal codes): the in-order fold of its faces' boxes,
-// which is the in-order fold of their vertices.
-__global__ __launch_bounds__(THREADS) void leaf_aabb_kernel(
-    const float *__restrict__ faceBoxes, const uint32_t *__restrict__ faces,
-    const uint32_t *__restrict__ compacted, const kk_lbvh_device_data *__restrict__ hdr,
-    float *__restrict__ leafAABBs) {
-    const uint32_t M = hdr->compacted_face_num;
-    const uint32_t N = hdr->face_num;
-    const uint32_t c = blockIdx.x * THREADS + threadIdx.x;
-    if (c >= M)
-        return;
-    const uint32_t beg = compacted[c];
-    const uint32_t end = (c == M - 1) ? N : compacted[c + 1];
-    AABB box = AABB::Initial();
-    for (uint32_t k = beg; k < end; ++k) {
-        const float4 *fb = reinterpret_cast<const float4 *>(faceBoxes + 8ull * faces[k]);
-        const float4 lo = fb[0], hi = fb[1];
-        AABB one;
-        one.minPos = {lo.x, lo.y, lo.z};
-        one.maxPos = {lo.w, hi.x, hi.y};
-        box.Expand(one);
-    }
-    store_box(leafAABBs + 6ull * c, box);
-}
-
 // lbvh.cu:221-232: length of the common leading-zero run of code[i] ^ code[j], -1 out of range.
 // Codes near the workgroup's own nodes come from LDS (most searches stay within a few hundred leaves).
-constexpr int KARRAS_HALO = 896;
-constexpr int KARRAS_WIN = THREADS + 2 * KARRAS_HALO;
-struct Codes {
-    const uint32_t *__restrict__ global;
+constexpr int KARRAS_THREADS = 512; // the halo is loaded once per workgroup
+constexpr int KARRAS_HALO = 1024;
+constexpr int KARRAS_WIN = KARRAS_THREADS + 2 * KARRAS_HALO;
+static_assert(KARRAS_WIN % KARRAS_THREADS == 0, "the window is loaded in whole rounds of the workgroup");
+// Two sources of codes for the search. The window in LDS serves nearly every node; a search that
+// leaves it is flagged and run again from global memory afterwards. The common path thus waits for
+// LDS only, and loads from global memory that are in flight beside it (the leaf's box) stay in flight.
+struct WindowCodes {
     const uint32_t *lds;
     int winStart;
-    __device__ __forceinline__ uint32_t operator[](int j) const {
+    bool escaped;
+    __device__ __forceinline__ bool fetch(int j, uint32_t &code) {
         const int r = j - winStart;
-        return (r >= 0 && r < KARRAS_WIN) ? lds[r] : global[j];
+        if (r < 0 || r >= KARRAS_WIN) {
+            escaped = true;
+            return false;
+        }
+        code = lds[r];
+        return true;
     }
 };
-__device__ __forceinline__ int delta(const Codes &m, uint32_t mi, int j, int inodeNum) {
-    if (j < 0 || j > inodeNum)
+struct GlobalCodes {
+    const uint32_t *__restrict__ global;
+    __device__ __forceinline__ bool fetch(int j, uint32_t &code) {
+        code = global[j];
+        return true;
+    }
+};
+template <class C> __device__ __forceinline__ int delta(C &m, uint32_t mi, int j, int inodeNum) {
+    uint32_t other;
+    if (j < 0 || j > inodeNum || !m.fetch(j, other))
         return -1;
-    const uint32_t x = mi ^ m[j];
+    const uint32_t x = mi ^ other;
     return x == 0 ? 32 : __clz(static_cast<int>(x));
 }
 
-// lbvh.cu:29-98, one thread per internal node. PARENTS also records the parent of each child (an
-// inspection stage; nothing in the build reads it).
-template <bool PARENTS>
-__global__ __launch_bounds__(THREADS) void karras_links_kernel(
-    const uint32_t *__restrict__ mortonsGlobal, const kk_lbvh_device_data *__restrict__ hdr,
-    kk_lbvh_node *__restrict__ nodes, uint32_t *__restrict__ nodeParents,
-    uint32_t *__restrict__ leafParents, uint32_t *__restrict__ rangeEnds) {
-    __shared__ uint32_t s_codes[KARRAS_WIN];
-    const uint32_t M = hdr->compacted_face_num;
-    // 32-bit positions: the leaf count is below 2^30 and a search looks at most one power of two past
-    // the range, so i +- offset stays inside an int
-    const int inodeNum = static_cast<int>(M) - 1;
-    const int blockFirst = static_cast<int>(blockIdx.x) * THREADS;
-    if (blockFirst >= inodeNum)
-        return;
-    Codes mortons{mortonsGlobal, s_codes, blockFirst - KARRAS_HALO};
-    for (int r = threadIdx.x; r < KARRAS_WIN; r += THREADS) {
-        const int j = mortons.winStart + r;
-        s_codes[r] = (j >= 0 && j <= inodeNum) ? mortonsGlobal[j] : 0u;
-    }
-    __syncthreads();
-    const int i = blockFirst + static_cast<int>(threadIdx.x);
-    if (i >= inodeNum)
-        return;
-    const uint32_t mi = mortons[i];
-
-    const int commLft = delta(mortons, mi, i - 1, inodeNum);
-    const int commRht = delta(mortons, mi, i + 1, inodeNum);
+// lbvh.cu:29-98: the other end of node i's leaf range and its split position. `afterFirstStage` runs
+// between the first and the second stage of the search (the caller's place to ask for memory).
+struct RangeAndSplit {
+    int iMax, split;
+};
+template <class C, class F>
+__device__ __forceinline__ RangeAndSplit karras_search(C &mortons, uint32_t mi, int i, int inodeNum, bool hasNode,
+                                                       F &&afterFirstStage) {
+    // a thread without a node (the last leaf's) skips the search: cmp = 33 ends every loop at once
+    const int commLft = hasNode ? delta(mortons, mi, i - 1, inodeNum) : 0;
+    const int commRht = hasNode ? delta(mortons, mi, i + 1, inodeNum) : 0;
     const int d = (commLft <= commRht) ? 1 : -1;
 
-    int cmp = delta(mortons, mi, i - d, inodeNum);
+    int cmp = hasNode ? delta(mortons, mi, i - d, inodeNum) : 33;
     int offsMax = 2;
     while (delta(mortons, mi, i + d * offsMax, inodeNum) > cmp)
         offsMax <<= 1;
+    afterFirstStage();
 
     int offs = 0;
     while (true) {
@@ -410,8 +387,9 @@ __global__ __launch_bounds__(THREADS) void karras_links_kernel(
         if (delta(mortons, mi, i + d * (offsMax + offs), inodeNum) > cmp)
             offs += offsMax;
     }
-    const int iMax = i + d * offs;
-    cmp = delta(mortons, mi, iMax, inodeNum);
+    RangeAndSplit r;
+    r.iMax = i + d * offs;
+    cmp = delta(mortons, mi, r.iMax, inodeNum);
 
     offsMax = offs;
     offs = 0;
@@ -424,12 +402,75 @@ __global__ __launch_bounds__(THREADS) void karras_links_kernel(
         if (offsMax == 1)
             break;
     }
-    const int split = i + d * offs + (d < 0 ? -1 : 0);
+    r.split = i + d * offs + (d < 0 ? -1 : 0);
+    return r;
+}
+
+// lbvh.cu:29-98, one thread per internal node. PARENTS also records the parent of each child (an
+// inspection stage; nothing in the build reads it).
+//
+// Thread i also makes the box of leaf i (lbvh.cu:186-219: the in-order fold of the boxes of its faces,
+// which is the in-order fold of their vertices). Its three dependent loads - where the run starts, the
+// run's first face, that face's box - are random gathers bound by DRAM; the search is bound by issue and
+// LDS. Each load is asked for before a stage of the search and used after it, so one hides the other.
+template <bool PARENTS>
+__global__ __launch_bounds__(KARRAS_THREADS) void karras_links_kernel(
+    const uint32_t *__restrict__ mortonsGlobal, const kk_lbvh_device_data *__restrict__ hdr,
+    kk_lbvh_node *__restrict__ nodes, uint32_t *__restrict__ nodeParents,
+    uint32_t *__restrict__ leafParents, uint32_t *__restrict__ rangeEnds,
+    const float *__restrict__ faceBoxes, const uint32_t *__restrict__ faces,
+    const uint32_t *__restrict__ compacted, float *__restrict__ leafAABBs) {
+    __shared__ uint32_t s_codes[KARRAS_WIN];
+    const uint32_t M = hdr->compacted_face_num;
+    // 32-bit positions: the leaf count is below 2^30 and a search looks at most one power of two past
+    // the range, so i +- offset stays inside an int
+    const int inodeNum = static_cast<int>(M) - 1;
+    const int blockFirst = static_cast<int>(blockIdx.x) * KARRAS_THREADS;
+    if (blockFirst > inodeNum)
+        return;
+    const int i = blockFirst + static_cast<int>(threadIdx.x);
+    const bool hasLeaf = i <= inodeNum, hasNode = i < inodeNum;
+    uint32_t faceBeg = 0, faceEnd = 0;
+    if (hasLeaf) {
+        faceBeg = compacted[i];
+        faceEnd = (i == inodeNum) ? hdr->face_num : compacted[i + 1];
+    }
+    WindowCodes window{s_codes, blockFirst - KARRAS_HALO, false};
+    {
+        // every load of the window is asked for before the first is waited for: positions outside the
+        // array are clamped into it (delta() never looks at those entries), so no load hides in a branch
+        uint32_t code[KARRAS_WIN / KARRAS_THREADS];
+#pragma unroll
+        for (int q = 0; q < KARRAS_WIN / KARRAS_THREADS; ++q) {
+            int j = window.winStart + static_cast<int>(threadIdx.x) + q * KARRAS_THREADS;
+            j = j < 0 ? 0 : (j > inodeNum ? inodeNum : j);
+            code[q] = mortonsGlobal[j];
+        }
+#pragma unroll
+        for (int q = 0; q < KARRAS_WIN / KARRAS_THREADS; ++q)
+            s_codes[threadIdx.x + q * KARRAS_THREADS] = code[q];
+    }
+    __syncthreads();
+    if (!hasLeaf)
+        return;
+    const uint32_t firstFace = faces[faceBeg];
+    const uint32_t mi = s_codes[static_cast<int>(threadIdx.x) + KARRAS_HALO];
+    float4 boxLo = make_float4(0.f, 0.f, 0.f, 0.f), boxHi = boxLo;
+    RangeAndSplit found = karras_search(window, mi, i, inodeNum, hasNode, [&]() {
+        const float4 *fb = reinterpret_cast<const float4 *>(faceBoxes + 8ull * firstFace);
+        boxLo = fb[0];
+        boxHi = fb[1];
+    });
+    if (window.escaped) {
+        GlobalCodes all{mortonsGlobal};
+        found = karras_search(all, mi, i, inodeNum, hasNode, []() {});
+    }
+    const int iMax = found.iMax, split = found.split;
 
     uint32_t lft = static_cast<uint32_t>(split);
     uint32_t rht = static_cast<uint32_t>(split + 1);
     const int lo = i < iMax ? i : iMax, hi = i < iMax ? iMax : i;
-    if (PARENTS) {
+    if (PARENTS && hasNode) {
         (lo == split ? leafParents : nodeParents)[lft] = static_cast<uint32_t>(i);
         (hi == split + 1 ? leafParents : nodeParents)[rht] = static_cast<uint32_t>(i);
         if (i == 0)
@@ -439,8 +480,23 @@ __global__ __launch_bounds__(THREADS) void karras_links_kernel(
         lft |= LEAF;
     if (hi == split + 1)
         rht |= LEAF;
-    *reinterpret_cast<uint2 *>(&nodes[i].lft) = make_uint2(lft, rht);
-    rangeEnds[i] = static_cast<uint32_t>(iMax); // the node covers leaves [min(i, iMax), max(i, iMax)]
+    if (hasNode) {
+        *reinterpret_cast<uint2 *>(&nodes[i].lft) = make_uint2(lft, rht);
+        rangeEnds[i] = static_cast<uint32_t>(iMax); // the node covers leaves [min(i, iMax), max(i, iMax)]
+    }
+
+    AABB box;
+    box.minPos = {boxLo.x, boxLo.y, boxLo.z};
+    box.maxPos = {boxLo.w, boxHi.x, boxHi.y};
+    for (uint32_t k = faceBeg + 1; k < faceEnd; ++k) { // a leaf of several faces with one code
+        const float4 *fb = reinterpret_cast<const float4 *>(faceBoxes + 8ull * faces[k]);
+        const float4 l4 = fb[0], h4 = fb[1];
+        AABB one;
+        one.minPos = {l4.x, l4.y, l4.z};
+        one.maxPos = {l4.w, h4.x, h4.y};
+        box.Expand(one);
+    }
+    store_box(leafAABBs + 6ull * i, box);
 }
 
 
@@ -820,15 +876,15 @@ extern "C" int kk_lbvh_build(const float *d_positions, uint32_t vert_num,
                                                                uniq);
     KK_LAUNCH_CHECK();
 
-    const uint32_t ngrid = div_up(N, THREADS);
-    leaf_aabb_kernel<<<ngrid, THREADS, 0, stream>>>(faceBoxes, d_faces, d_compacted, d_out, leafAABBs);
-    KK_LAUNCH_CHECK();
+    const uint32_t ngrid = div_up(N, KARRAS_THREADS);
     if (flags & KK_LBVH_KEEP_STAGES)
-        karras_links_kernel<true><<<ngrid, THREADS, 0, stream>>>(uniq, d_out, d_nodes, nodeParents,
-                                                                 leafParents, rangeEnds);
+        karras_links_kernel<true><<<ngrid, KARRAS_THREADS, 0, stream>>>(uniq, d_out, d_nodes, nodeParents, leafParents,
+                                                                 rangeEnds, faceBoxes, d_faces, d_compacted,
+                                                                 leafAABBs);
     else
-        karras_links_kernel<false><<<ngrid, THREADS, 0, stream>>>(uniq, d_out, d_nodes, nodeParents,
-                                                                  leafParents, rangeEnds);
+        karras_links_kernel<false><<<ngrid, KARRAS_THREADS, 0, stream>>>(uniq, d_out, d_nodes, nodeParents, leafParents,
+                                                                  rangeEnds, faceBoxes, d_faces, d_compacted,
+                                                                  leafAABBs);
     KK_LAUNCH_CHECK();
     KK_HIP_TRY(hipMemsetAsync(topCount, 0, 4, stream));
     const TotalsLayout tl = totals_layout(N);

@@ -213,7 +213,7 @@ __global__ __launch_bounds__(THREADS) void onesweep_pass_kernel(
         if (tile != 0) {
             // look back over the predecessors, LOOK of them per round trip to memory: their words are
             // read together and used in order, up to the first that is not published yet
-            constexpr uint32_t LOOK = 4;
+            constexpr uint32_t LOOK = 4; // wider (8, 16, 32) was measured: no faster, the wait is not here
             uint32_t t = tile - 1;
             uint32_t spins = 0;
             bool done = false;
@@ -222,25 +222,27 @@ __global__ __launch_bounds__(THREADS) void onesweep_pass_kernel(
 #pragma unroll
                 for (uint32_t u = 0; u < LOOK; ++u)
                     s[u] = u <= t ? ld_status(tileStatus + static_cast<size_t>(t - u) * RADIX + dg) : 0u;
+                bool open = true; // the words are used in order up to the first that is not there
+                uint32_t used = 0;
 #pragma unroll
                 for (uint32_t u = 0; u < LOOK; ++u) {
                     const uint32_t f = s[u] & FLAG_MASK;
-                    if (f == 0) { // tile t not there yet: read again from it
-                        if (u == 0) {
-                            if (++spins > SPIN_LIMIT) {
-                                atomicOr(errorFlag, 1u);
-                                done = true;
-                            } else
-                                __builtin_amdgcn_s_sleep(2);
-                        }
-                        break;
+                    const bool ready = open && u <= t && f != 0u;
+                    exclusive += ready ? (s[u] & VALUE_MASK) : 0u;
+                    used += ready ? 1u : 0u;
+                    const bool last = ready && (f == FLAG_INC || u == t);
+                    done = done || last;
+                    open = ready && !last;
+                }
+                if (!done) {
+                    if (used == 0u) { // tile t not published yet: read again from it
+                        if (++spins > SPIN_LIMIT) {
+                            atomicOr(errorFlag, 1u);
+                            done = true;
+                        } else
+                            __builtin_amdgcn_s_sleep(2);
                     }
-                    exclusive += s[u] & VALUE_MASK;
-                    if (f == FLAG_INC || t == 0) {
-                        done = true;
-                        break;
-                    }
-                    --t;
+                    t -= used;
                 }
             }
             st_status(row, ((exclusive + total) & VALUE_MASK) | FLAG_INC);

@@ -52,7 +52,11 @@ constexpr float LEAF_PAD = 1e-5f; // leaf boxes grow by this fraction of the sce
 // A binary path fixes one more Morton bit per level, a wide level descends at least one binary level.
 constexpr int MAX_LEVELS = 32;
 struct alignas(256) BuildCtl {
-    uint32_t wideCount, triCount;
+    // reserved so far; one 64-bit word (low half: triangle records, high half: wide nodes) so that a
+    // workgroup reserves both with a single atomic. Every reservation of a level goes to this one
+    // address, and atomics on one address are served one after the other: a level of a million nodes is
+    // bound by their number, not by the work.
+    uint32_t triCount, wideCount;
     uint32_t bounds[MAX_LEVELS + 2]; // wide nodes of level l are [bounds[l], bounds[l + 1])
 };
 
@@ -63,6 +67,7 @@ struct alignas(256) BuildCtl {
 // with a box each. Which triangles are candidates is unchanged (every triangle still carries its
 // leaf's parent for the acceptance test); fewer of them are met.
 constexpr uint32_t SPLIT_MIN = 4, SPLIT_MAX = 120; // 8 chunks of at most 15 (the count nibbles)
+constexpr uint32_t LINKS_IN_NODE = 0xFFFFFFFFu; // collapse: a subtree slot whose links are not packed
 constexpr uint32_t RUN_FLAG = 0x40000000u;          // rootOf: low bits = leaf index instead of a binary node
 
 struct Layout {
@@ -182,7 +187,7 @@ __global__ __launch_bounds__(THREADS) void fill_records_kernel(const kk_lbvh_dev
     o[2] = make_uint4(__float_as_uint(c.x), __float_as_uint(c.y), __float_as_uint(c.z), src.x);
 }
 
-constexpr int BT = 128; // threads of a collapse workgroup: 16 KB of slot storage in LDS
+constexpr int BT = 256; // threads of a collapse workgroup: 36 KB of slot storage in LDS, four workgroups per CU
 
 // Runs between two levels: the wide nodes reserved so far end the level that is built next.
 __global__ void close_level_kernel(BuildCtl *ctl, Header *hdr, int level) {
@@ -195,11 +200,24 @@ __global__ void close_level_kernel(BuildCtl *ctl, Header *hdr, int level) {
 // slots, reserves its children's wide nodes and its triangles' records, and writes the node and the
 // records' sources. Slot boxes are quantised as they are met, against the subtree's own box (grown by
 // the leaf pad), which contains them all. Workgroup `group` of `groups` takes every groups-th batch.
+// The byte boxes of eight slots per thread: six bytes each, kept as a word and a half word so that a
+// collapse workgroup of 256 threads stays within a quarter of a CU's LDS.
+struct SlotBoxes {
+    uint32_t lo[8][BT];       // minx miny minz maxx
+    unsigned short hi[8][BT]; // maxy maxz
+    __device__ __forceinline__ uint2 get(int j, int tid) const { return make_uint2(lo[j][tid], hi[j][tid]); }
+    __device__ __forceinline__ void set(int j, int tid, uint2 v) {
+        lo[j][tid] = v.x;
+        hi[j][tid] = static_cast<unsigned short>(v.y);
+    }
+};
 struct CollapseLds {
-    uint2 q[8][BT];      // x: minx miny minz maxx (bytes), y: maxy maxz
+    SlotBoxes q;
     uint32_t ref[8][BT]; // binary node, or LEAF | leaf index
     uint32_t aux[8][BT]; // leaf: its parent binary node; subtree: half box area (float)
-    uint32_t len[8][BT]; // leaf: its triangles
+    uint2 waveTotal[BT / 64];    // x: triangle records, y: wide nodes asked for by a wave
+    unsigned long long reserved; // what the workgroup's reservation returned
+    uint32_t len[8][BT]; // leaf: its triangles; subtree: its two links in one word (or LINKS_IN_NODE)
 };
 // Quantisation frame of a wide node: its box grown by the pad, 2^ex per byte unit and axis.
 struct QFrame {
@@ -231,10 +249,10 @@ __device__ __forceinline__ uint2 quantise_box(const AABB &b, const QFrame &f) {
 }
 // slot = octant of the child's centre around the node's centre, nearest free one; 4 bits per slot of the
 // result: which of the cN children (byte boxes q[j * stride]) sits there (0xF: none)
-__device__ __forceinline__ uint32_t assign_slots(int cN, const QFrame &f, const uint2 *q, int stride) {
+__device__ __forceinline__ uint32_t assign_slots(int cN, const QFrame &f, const SlotBoxes &q, int tid) {
     uint32_t used = 0, childOf = 0xFFFFFFFFu;
     for (int j = 0; j < cN; ++j) {
-        const uint2 b = q[j * stride];
+        const uint2 b = q.get(j, tid);
         // (centre of the slot - centre of the node) * 2, in world units
         const float dx = ldexpf(static_cast<float>((b.x & 0xffu) + (b.x >> 24)) - f.extQ.x, f.ex[0]);
         const float dy = ldexpf(static_cast<float>(((b.x >> 8) & 0xffu) + (b.y & 0xffu)) - f.extQ.y, f.ex[1]);
@@ -324,22 +342,36 @@ __device__ __forceinline__ void collapse_range(CollapseLds &lds, const CollapseA
             const uint32_t n = root;
             const trav::NodeData me = trav::load_node(nodes, n);
             fr = make_frame(me.box.minPos, me.box.maxPos, pad);
+            // Everything a slot will be asked for later comes with the one round of loads that brings its
+            // box: a leaf's triangle count, a subtree's two links (packed into one word when the right
+            // child's index is the left one's plus one, as the builder numbers them; LINKS_IN_NODE: read
+            // them from the node when it is opened). The loop below then waits for memory once per child
+            // opened, not three times.
             auto put = [&](int j, uint32_t c, uint32_t parent) {
                 AABB b;
-                uint32_t aux;
+                uint32_t aux, extra;
                 if (c & LEAF) {
-                    const float *lb = leafBoxes + 6ull * (c & LEAF_MASK);
+                    const uint32_t l = c & LEAF_MASK;
+                    const float *lb = leafBoxes + 6ull * l;
+                    const uint32_t k0 = compacted[l];
+                    const uint32_t k1 = (l == leafNum - 1) ? faceNum : compacted[l + 1];
                     b.minPos = F3(lb[0], lb[1], lb[2]) - pad;
                     b.maxPos = F3(lb[3], lb[4], lb[5]) + pad;
                     aux = parent;
+                    extra = k1 - k0;
                 } else {
-                    b = trav::load_node(nodes, c).box;
+                    const trav::NodeData nd = trav::load_node(nodes, c);
+                    b = nd.box;
                     const f3 e = b.maxPos - b.minPos;
                     aux = __float_as_uint(e.x * e.y + e.y * e.z + e.z * e.x);
+                    const uint32_t li = nd.lft & LEAF_MASK, ri = nd.rht & LEAF_MASK;
+                    extra = (ri == li + 1u && li < 0x3FFFFFFFu) ? (li | (nd.lft & LEAF) | ((nd.rht & LEAF) >> 1))
+                                                              : LINKS_IN_NODE;
                 }
-                s_q[j][tid] = quantise_box(b, fr);
+                s_q.set(j, tid, quantise_box(b, fr));
                 s_ref[j][tid] = c;
                 s_aux[j][tid] = aux;
+                lds.len[j][tid] = extra;
             };
             put(0, me.lft, n);
             cN = 1;
@@ -361,24 +393,24 @@ __device__ __forceinline__ void collapse_range(CollapseLds &lds, const CollapseA
                 if (pick < 0)
                     break;
                 const uint32_t c = s_ref[pick][tid];
-                const uint2 ch = *reinterpret_cast<const uint2 *>(nodes + c);
+                const uint32_t packed = lds.len[pick][tid];
+                uint2 ch;
+                if (packed != LINKS_IN_NODE) {
+                    ch.x = (packed & 0x3FFFFFFFu) | (packed & LEAF);
+                    ch.y = ((packed & 0x3FFFFFFFu) + 1u) | ((packed << 1) & LEAF);
+                } else
+                    ch = *reinterpret_cast<const uint2 *>(nodes + c);
                 put(pick, ch.x, c);
                 put(cN, ch.y, c);
                 ++cN;
             }
-            childOf = assign_slots(cN, fr, &s_q[0][tid], BT);
+            childOf = assign_slots(cN, fr, s_q, tid);
             for (int sl = 0; sl < 8; ++sl) {
                 const uint32_t j = (childOf >> (4 * sl)) & 0xFu;
                 if (j == 0xFu)
                     continue;
                 const uint32_t ref = s_ref[j][tid];
-                uint32_t len = 0u;
-                if (ref & LEAF) {
-                    uint32_t k0, k1;
-                    runOf(ref, k0, k1);
-                    len = k1 - k0;
-                    lds.len[j][tid] = len;
-                }
+                const uint32_t len = (ref & LEAF) ? lds.len[j][tid] : 0u;
                 if ((ref & LEAF) && !splits(len)) {
                     leafMask |= 1u << sl;
                     ct += len;
@@ -387,7 +419,7 @@ __device__ __forceinline__ void collapse_range(CollapseLds &lds, const CollapseA
             }
             ci = __popc(imask);
         }
-        // one reservation per wave
+        // one reservation per workgroup
         uint32_t ciIncl = ci, ctIncl = ct;
         for (int o = 1; o < 64; o <<= 1) {
             const uint32_t a = __shfl_up(ciIncl, o, 64), b = __shfl_up(ctIncl, o, 64);
@@ -396,15 +428,24 @@ __device__ __forceinline__ void collapse_range(CollapseLds &lds, const CollapseA
                 ctIncl += b;
             }
         }
-        uint32_t childBase = 0, triBase = 0;
-        if (lane == 63) {
-            if (ciIncl)
-                childBase = atomicAdd(&ctl->wideCount, ciIncl);
-            if (ctIncl)
-                triBase = atomicAdd(&ctl->triCount, ctIncl);
+        const int wave = tid >> 6;
+        if (lane == 63)
+            lds.waveTotal[wave] = make_uint2(ctIncl, ciIncl);
+        __syncthreads();
+        if (tid == 0) {
+            unsigned long long all = 0ull;
+            for (int wv = 0; wv < BT / 64; ++wv)
+                all += lds.waveTotal[wv].x | (static_cast<unsigned long long>(lds.waveTotal[wv].y) << 32);
+            lds.reserved = all ? atomicAdd(reinterpret_cast<unsigned long long *>(&ctl->triCount), all) : 0ull;
         }
-        childBase = __shfl(childBase, 63, 64) + (ciIncl - ci);
-        triBase = __shfl(triBase, 63, 64) + (ctIncl - ct);
+        __syncthreads();
+        uint32_t triBase = static_cast<uint32_t>(lds.reserved) + (ctIncl - ct);
+        uint32_t childBase = static_cast<uint32_t>(lds.reserved >> 32) + (ciIncl - ci);
+        for (int wv = 0; wv < wave; ++wv) {
+            triBase += lds.waveTotal[wv].x;
+            childBase += lds.waveTotal[wv].y;
+        }
+        __syncthreads(); // the totals are written again in the next batch
         if (!valid)
             continue;
 
@@ -423,6 +464,14 @@ __device__ __forceinline__ void collapse_range(CollapseLds &lds, const CollapseA
         rec.triBase = triBase;
         uint32_t counts = 0, longest = 0;
         uint32_t rank = 0, run = 0;
+        uint32_t firstOf[8]; // the leaf slots' first triangles, asked for together
+#pragma unroll
+        for (int sl = 0; sl < 8; ++sl) {
+            const uint32_t j = (childOf >> (4 * sl)) & 0xFu;
+            const uint32_t ref = j == 0xFu ? 0u : s_ref[j][tid];
+            firstOf[sl] = (ref & LEAF) ? compacted[ref & LEAF_MASK] : 0u;
+        }
+#pragma unroll
         for (int sl = 0; sl < 8; ++sl) {
             rec.off16[sl] = rec.cnt16[sl] = 0;
             const uint32_t j = (childOf >> (4 * sl)) & 0xFu;
@@ -430,7 +479,7 @@ __device__ __forceinline__ void collapse_range(CollapseLds &lds, const CollapseA
                 set_slot_empty(rec, sl);
                 continue;
             }
-            set_slot_box(rec, sl, s_q[j][tid]);
+            set_slot_box(rec, sl, s_q.get(j, tid));
             const uint32_t ref = s_ref[j][tid];
             if (!(ref & LEAF)) {
                 rootOf[childBase + rank] = ref;
@@ -444,7 +493,7 @@ __device__ __forceinline__ void collapse_range(CollapseLds &lds, const CollapseA
                 ++rank;
                 continue;
             }
-            const uint32_t k0 = compacted[ref & LEAF_MASK];
+            const uint32_t k0 = firstOf[sl];
             const uint32_t parent = s_aux[j][tid];
             for (uint32_t k = k0; k < k0 + len; ++k)
                 recSrc[triBase + run + (k - k0)] = make_uint2(k, parent);
@@ -467,7 +516,7 @@ __device__ __forceinline__ void collapse_range(CollapseLds &lds, const CollapseA
 // leaf's triangles in the order of their centres along the longest axis of those, cut into up to eight
 // chunks of equal length, each with the box of its own triangles.
 __global__ __launch_bounds__(BT) void run_nodes_kernel(CollapseArgs args, const Header *__restrict__ hdr) {
-    __shared__ uint2 s_q[8][BT];
+    __shared__ SlotBoxes s_q;
     const int tid = threadIdx.x;
     const uint32_t w = blockIdx.x * BT + tid;
     if (w >= hdr->wideNum)
@@ -524,9 +573,9 @@ __global__ __launch_bounds__(BT) void run_nodes_kernel(CollapseArgs args, const 
                 b.Expand(corner(order[i], c));
         b.minPos = b.minPos - pad;
         b.maxPos = b.maxPos + pad;
-        s_q[j][tid] = quantise_box(b, fr);
+        s_q.set(j, tid, quantise_box(b, fr));
     }
-    const uint32_t childOf = assign_slots(cN, fr, &s_q[0][tid], BT);
+    const uint32_t childOf = assign_slots(cN, fr, s_q, tid);
     Wide8 rec;
     for (int a = 0; a < 3; ++a) {
         rec.origin[a] = fr.org[a];
@@ -543,7 +592,7 @@ __global__ __launch_bounds__(BT) void run_nodes_kernel(CollapseArgs args, const 
             set_slot_empty(rec, sl);
             continue;
         }
-        set_slot_box(rec, sl, s_q[j][tid]);
+        set_slot_box(rec, sl, s_q.get(j, tid));
         const uint32_t len = chunkAt[j + 1] - chunkAt[j]; // <= 15
         for (uint32_t i = chunkAt[j]; i < chunkAt[j + 1]; ++i)
             args.recSrc[triBase + run + (i - chunkAt[j])] = make_uint2(k0 + order[i], parent);
