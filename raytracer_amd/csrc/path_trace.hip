@@ -402,7 +402,12 @@ constexpr uint32_t COUNTER_SLOTS = 64;
 // Queue heads of the launches in flight: a launch takes the next slot and clears it on its stream
 // first. (Launches more than COUNTER_SLOTS apart share a slot; they cannot overlap unless that many
 // are in flight on one GPU at once.)
-static __device__ uint32_t g_pixelQueue[COUNTER_SLOTS * 32];
+// One word takes about 88 returning atomics per microsecond, which a frame's ~70 000 refills of a
+// single-sample launch would use up: the pixels are handed out from PIXEL_QUEUES queues (every
+// PIXEL_QUEUES-th tile each, so that all hold the same mix of cheap and costly pixels; a wave starts at
+// the queue of its XCD and moves on when that is used up), their heads 128 bytes apart.
+constexpr uint32_t PIXEL_QUEUES = 8, HEAD_STRIDE = 32, SLOT_WORDS = PIXEL_QUEUES * HEAD_STRIDE;
+static __device__ uint32_t g_pixelQueue[COUNTER_SLOTS * SLOT_WORDS];
 
 struct PathState {
     // the path
@@ -444,7 +449,11 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(WAVES, 
 
     const uint32_t tilesX = (static_cast<uint32_t>(W) + 7u) >> 3;
     const uint32_t tilesY = (static_cast<uint32_t>(y1 - y0) + 7u) >> 3;
-    const uint32_t queueLen = tilesX * tilesY * 64u;
+    // A launch of several samples per pixel asks its queue sixteen times less often than its pixels take
+    // to render: one queue serves it (and keeps the kernel's registers for the walk).
+    constexpr uint32_t NQ = WAVES == WAVES_LONG ? 1u : PIXEL_QUEUES;
+    const uint32_t tileNum = tilesX * tilesY; // queue q hands out the tiles q, q + NQ, ...
+    uint32_t queue = NQ == 1u ? 0u : (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xfu) % NQ, queuesTried = 0; // XCC_ID
     // a lane renders samples sampleFirst .. sampleFirst + sampleCount - 1 of its pixel one after the other
     // (the running mean of a pixel is order dependent) before it takes another pixel
     const uint32_t sampleFirst = static_cast<uint32_t>(sampleIdx);
@@ -745,16 +754,20 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(WAVES, 
             if (idleMask != 0ull && !poolEmpty) {
                 const uint32_t want = __popcll(idleMask);
                 const int leader = __ffsll(static_cast<long long>(idleMask)) - 1;
+                const uint32_t qLen = (tileNum + NQ - 1u - queue) / NQ * 64u;
+                const uint32_t firstTile = queue; // before `queue` moves on
                 uint32_t base = 0;
                 if (lane == leader)
-                    base = atomicAdd(pixelQueue, want);
+                    base = atomicAdd(pixelQueue + queue * HEAD_STRIDE, want);
                 base = __shfl(base, leader, 64);
-                if (base + want >= queueLen || base + want < base)
-                    poolEmpty = true; // wave-uniform
+                if (base + want >= qLen || base + want < base) { // used up: the next refill asks the next queue
+                    queue = queue + 1u == NQ ? 0u : queue + 1u;
+                    poolEmpty = ++queuesTried == NQ; // wave-uniform
+                }
                 if (stage == ST_IDLE) {
                     const uint32_t q = base + __popcll(idleMask & lanesBelow);
-                    if (q < queueLen && q >= base) {
-                        const uint32_t tile = q >> 6, in = q & 63u;
+                    if (q < qLen && q >= base) {
+                        const uint32_t tile = (q >> 6) * NQ + firstTile, in = q & 63u;
                         const uint32_t tx = tile % tilesX, ty = tile / tilesX;
                         const int x = static_cast<int>(tx * 8u + (in & 7u));
                         const int y = y0 + static_cast<int>(ty * 8u + (in >> 3));
@@ -919,8 +932,8 @@ extern "C" int kk_pt_render_samples(const kk_lbvh_device_data *d_lbvh, const kk_
         if (rc != KK_OK)
             return rc;
         static std::atomic<uint32_t> nextSlot{0};
-        uint32_t *head = queues + 32u * (nextSlot.fetch_add(1u) % persist::COUNTER_SLOTS);
-        KK_HIP_TRY(hipMemsetAsync(head, 0, sizeof(uint32_t), stream));
+        uint32_t *head = queues + persist::SLOT_WORDS * (nextSlot.fetch_add(1u) % persist::COUNTER_SLOTS);
+        KK_HIP_TRY(hipMemsetAsync(head, 0, sizeof(uint32_t) * persist::SLOT_WORDS, stream));
         const uint32_t queueLen = div_up(width, 8) * div_up(y1 - y0, 8) * 64u;
         uint32_t pgrid = div_up(queueLen, THREADS);
         const bool longLaunch = sample_count >= persist::LONG_LAUNCH_SAMPLES;
