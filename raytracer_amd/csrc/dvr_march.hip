@@ -35,15 +35,9 @@ struct HDDA3D {
     float tCurr, tNext;
     f3 tSide, tDlt;
 
-    KK_D void Prepare(const Ray &ray, f3 min, float voxPerChild) {
-        tDlt = vabs(voxPerChild / ray.dir);
-        const f3 pFlt = (ray.pos + tCurr * ray.dir - min) / voxPerChild;
-        const f3 fl = vfloor(pFlt);
-        tSide = ((fl - pFlt + .5f) * toF3(sign) + .5f) * tDlt + tCurr;
-        chPos = {static_cast<int>(fl.x), static_cast<int>(fl.y), static_cast<int>(fl.z)};
-    }
-    // The same values with the ray's |1 / dir| at hand: voxPerChild is a power of two, so scaling by it
-    // (or by its reciprocal) rounds exactly as the divisions above do.
+    // dda.h:41-50 divides by voxPerChild and divides voxPerChild by the direction. voxPerChild is a
+    // power of two, so scaling by it (or by its exact reciprocal) and by the ray's |1 / dir| rounds as
+    // those divisions do.
     KK_D void Prepare(const Ray &ray, f3 absInvDir, f3 min, float voxPerChild) {
         tDlt = absInvDir * voxPerChild;
         // 1 / 2^k, exact: the exponent field mirrored about the bias
@@ -76,53 +70,8 @@ struct DepthDDA2D {
     float t, tStart, dep, tDlt2Dep;
     f3 tSide, tDlt;
 
-    KK_D bool Init(float t_, float maxPosValInBrick, int minDepPos, int maxDepPos, f3 pib,
-                   const Ray &ray) {
-        dep = 0.f;
-        tDlt2Dep = 0.f;
-        sign = {sgn(ray.dir.x), sgn(ray.dir.y), sgn(ray.dir.z)};
-        mask = {0, 0, 0};
-        t = tStart = t_;
-        i3 depSign;
-        {
-            const f3 d = {sign.x == 0 ? INFINITY : sign.x > 0 ? pib.x : maxPosValInBrick - pib.x,
-                          sign.y == 0 ? INFINITY : sign.y > 0 ? pib.y : maxPosValInBrick - pib.y,
-                          sign.z == 0 ? INFINITY : sign.z > 0 ? pib.z : maxPosValInBrick - pib.z};
-            depSign.x = d.x < d.y && d.x <= d.z ? sign.x : 0;
-            depSign.y = d.y < d.z && d.y <= d.x ? sign.y : 0;
-            depSign.z = d.z < d.x && d.z <= d.y ? sign.z : 0;
-            if (depSign.x != 0 && d.x >= .5f)
-                return false;
-            if (depSign.y != 0 && d.y >= .5f)
-                return false;
-            if (depSign.z != 0 && d.z >= .5f)
-                return false;
-        }
-        tDlt = vabs(1.f / ray.dir);
-        const f3 fl = vfloor(pib);
-        posInBrick = {static_cast<int>(fl.x), static_cast<int>(fl.y), static_cast<int>(fl.z)};
-        tSide = ((fl - pib + .5f) * toF3(sign) + .5f) * tDlt + t;
-        if (depSign.x != 0) {
-            posInBrick.x = depSign.x == 1 ? minDepPos : maxDepPos;
-            sign.x = 0;
-            tSide.x = INFINITY;
-            tDlt2Dep = fabsf(ray.dir.x);
-        }
-        if (depSign.y != 0) {
-            posInBrick.y = depSign.y == 1 ? minDepPos : maxDepPos;
-            sign.y = 0;
-            tSide.y = INFINITY;
-            tDlt2Dep = fabsf(ray.dir.y);
-        }
-        if (depSign.z != 0) {
-            posInBrick.z = depSign.z == 1 ? minDepPos : maxDepPos;
-            sign.z = 0;
-            tSide.z = INFINITY;
-            tDlt2Dep = fabsf(ray.dir.z);
-        }
-        return (depSign.x | depSign.y | depSign.z) != 0;
-    }
-    // The same with the ray's direction signs and |1 / dir| at hand.
+    // dda.h:96-150, with the ray's direction signs and |1 / dir| at hand: the face the ray enters
+    // through is picked once instead of axis by axis.
     KK_D bool Init(float t_, float maxPosValInBrick, int minDepPos, int maxDepPos, f3 pib, i3 raySign,
                    f3 absInvDir, const Ray &ray) {
         dep = 0.f;
@@ -905,7 +854,8 @@ __global__ __launch_bounds__(THREADS) void vdb_target_kernel(const kk_vdb_device
         h.mask = {0, 0, 0};
         h.tCurr = tEnter + Eps;
         h.tNext = 0.f;
-        h.Prepare(ray, F3(0.f), pick3(p.voxs_per_child, p.root_lev));
+        const f3 absInvDir = vabs(1.f / ray.dir);
+        h.Prepare(ray, absInvDir, F3(0.f), pick3(p.voxs_per_child, p.root_lev));
         if (target == KK_VDB_TARGET_AABBS && lev == displayLev)
             blend((ray.pos + h.tCurr * ray.dir - toF3(nodes[lev - 1].pos)) / p.vox_per_vdb);
 
@@ -928,7 +878,7 @@ __global__ __launch_bounds__(THREADS) void vdb_target_kernel(const kk_vdb_device
                 nodes[lev - 1] = vdb.node_pools[p.node_starts[lev] + ch];
                 tExits[lev - 1] = pushedExit;
                 h.tCurr += Eps;
-                h.Prepare(ray, toF3(nodes[lev - 1].pos), p.voxs_per_child[lev]);
+                h.Prepare(ray, absInvDir, toF3(nodes[lev - 1].pos), p.voxs_per_child[lev]);
                 if (target == KK_VDB_TARGET_AABBS && lev == displayLev)
                     blend((ray.pos + h.tCurr * ray.dir - toF3(nodes[lev - 1].pos)) /
                           p.voxs_per_child[lev + 1]);
@@ -948,7 +898,7 @@ __global__ __launch_bounds__(THREADS) void vdb_target_kernel(const kk_vdb_device
                 } else if (target == KK_VDB_TARGET_DEPTHS) {
                     const f3 pib = ray.pos + tCurr * ray.dir - brickMin;
                     DepthDDA2D d;
-                    if (d.Init(tCurr, dims0f, p.min_dep_pos_val_in_brick, p.max_dep_pos_val_in_brick, pib, ray)) {
+                    if (d.Init(tCurr, dims0f, p.min_dep_pos_val_in_brick, p.max_dep_pos_val_in_brick, pib, h.sign, absInvDir, ray)) {
                         const float depNorm = static_cast<float>(depthAt(brick, d.posInBrick)) / dims0f;
                         rgb = {depNorm, depNorm, depNorm};
                     } else
@@ -960,7 +910,7 @@ __global__ __launch_bounds__(THREADS) void vdb_target_kernel(const kk_vdb_device
                     f3 pib = ray.pos + tCurr * ray.dir - brickMin;
                     bool skipped = false;
                     DepthDDA2D d;
-                    if (d.Init(tCurr, dims0f, p.min_dep_pos_val_in_brick, p.max_dep_pos_val_in_brick, pib, ray))
+                    if (d.Init(tCurr, dims0f, p.min_dep_pos_val_in_brick, p.max_dep_pos_val_in_brick, pib, h.sign, absInvDir, ray))
                         while (static_cast<float>(depthAt(brick, d.posInBrick)) > d.dep) {
                             if (d.t >= tLeafExit) {
                                 skipped = true;
@@ -985,7 +935,7 @@ __global__ __launch_bounds__(THREADS) void vdb_target_kernel(const kk_vdb_device
                 ++lev;
                 if (lev == p.root_lev + 1)
                     break;
-                h.Prepare(ray, toF3(nodes[lev - 1].pos), p.voxs_per_child[lev]);
+                h.Prepare(ray, absInvDir, toF3(nodes[lev - 1].pos), p.voxs_per_child[lev]);
             }
         }
     }
