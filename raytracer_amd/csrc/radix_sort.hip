@@ -3,8 +3,8 @@
 // src/ray_tracer/lbvh.cu:110,172 (stable: equal Morton codes keep ascending face index).
 //
 // One pass, per 4096-key tile (256 threads = 4 waves, 16 keys per lane):
-//   1. the tile takes its number from an atomic counter, so every lower-numbered tile has already
-//      started and the look-back below cannot wait on a tile that is not running;
+//   1. the tile is the workgroup's index: workgroups start in index order, so every lower-numbered
+//      tile has already started and the look-back below cannot wait on a tile that is not running;
 //   2. each wave ranks its 1024 keys among equal digits with eight 64-lane ballots per key
 //      (match-any) and a per-wave digit counter in LDS;
 //   3. thread d owns digit d: sums the four wave counters, publishes the tile's count for the digit
@@ -111,25 +111,27 @@ template <bool IOTA>
 __global__ __launch_bounds__(THREADS) void onesweep_pass_kernel(
     const uint32_t *__restrict__ keysIn, const uint32_t *__restrict__ valsIn,
     uint32_t *__restrict__ keysOut, uint32_t *__restrict__ valsOut, uint32_t n, uint32_t shift,
-    const uint32_t *__restrict__ ghist, uint32_t *tileStatus, uint32_t *tileCounter,
-    uint32_t *errorFlag) {
+    const uint32_t *__restrict__ ghist, uint32_t *tileStatus, uint32_t *errorFlag) {
     __shared__ uint32_t s_keys[TILE];
     __shared__ uint32_t s_vals[TILE];
     __shared__ uint32_t s_whist[WAVES][RADIX];
     __shared__ uint32_t s_digitStart[RADIX];
     __shared__ uint32_t s_globalBase[RADIX];
     __shared__ uint32_t s_tmp[WAVES];
-    __shared__ uint32_t s_tile;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
 
-    if (tid == 0)
-        s_tile = atomicAdd(tileCounter, 1u);
     for (int i = tid; i < WAVES * RADIX; i += THREADS)
         (&s_whist[0][0])[i] = 0;
     __syncthreads();
-    const uint32_t tile = s_tile;
+    // The tile is the workgroup's index. The look-back below waits for the tiles in front, so each of
+    // them must be running or done by then: workgroups of a grid are started in index order (every XCD
+    // takes its share in order) and all ask for the same resources, so none is passed over. (A ticket
+    // from an atomic counter would not lean on that order, but 2 442 returning atomics on one word cost
+    // 12 us per pass at 10 M keys.) Should the order ever not hold, the spin limit ends the wait and
+    // raises the error word.
+    const uint32_t tile = blockIdx.x;
     const uint32_t tileBase = tile * TILE;
 
     // 1. load: wave w owns keys [tileBase + 1024 w, +1024), item i of lane l is key 64 i + l of those
@@ -273,7 +275,7 @@ inline SortWs sort_ws(uint32_t n) {
     Carver c;
     w.tiles = div_up(n, TILE);
     w.ghist = c.take(sizeof(uint32_t) * HIST_COPIES * HIST_COPY_STRIDE);
-    w.counters = c.take(sizeof(uint32_t) * PASSES);
+    w.counters = c.take(sizeof(uint32_t) * PASSES); // unused (tile tickets once); keeps the error word's offset
     w.error = c.take(sizeof(uint32_t));
     w.status = c.take(sizeof(uint32_t) * PASSES * static_cast<size_t>(w.tiles) * RADIX);
     w.total = c.off;
@@ -306,7 +308,6 @@ int sort_pairs(uint32_t *keysA, uint32_t *keysB, uint32_t *valsA, uint32_t *vals
     }
     char *b = static_cast<char *>(ws);
     uint32_t *ghist = reinterpret_cast<uint32_t *>(b + w.ghist);
-    uint32_t *counters = reinterpret_cast<uint32_t *>(b + w.counters);
     uint32_t *error = reinterpret_cast<uint32_t *>(b + w.error);
     uint32_t *status = reinterpret_cast<uint32_t *>(b + w.status);
     if (errorFlagOut)
@@ -326,10 +327,10 @@ int sort_pairs(uint32_t *keysA, uint32_t *keysB, uint32_t *valsA, uint32_t *vals
         uint32_t *st = status + static_cast<size_t>(p) * w.tiles * RADIX;
         if (p == 0 && iota)
             onesweep_pass_kernel<true><<<w.tiles, THREADS, 0, stream>>>(
-                kin, nullptr, kout, vout, n, 8u * p, ghist + p * RADIX, st, counters + p, error);
+                kin, nullptr, kout, vout, n, 8u * p, ghist + p * RADIX, st, error);
         else
             onesweep_pass_kernel<false><<<w.tiles, THREADS, 0, stream>>>(
-                kin, vin, kout, vout, n, 8u * p, ghist + p * RADIX, st, counters + p, error);
+                kin, vin, kout, vout, n, 8u * p, ghist + p * RADIX, st, error);
         KK_LAUNCH_CHECK();
         uint32_t *t = kin;
         kin = kout;
