@@ -159,6 +159,29 @@ def main():
     ev1.record()
     torch.cuda.synchronize()
     kernel_ms = ev0.elapsed_time(ev1) / K
+    # two batches in flight: steps alternate over two streams, each with its own outputs and workspace, so
+    # that one step's key + sort and the tail of its trace run beside the other's trace (what a renderer
+    # with independent ray batches would do; `value` above stays one step at a time)
+    in_flight = None
+    if world == 1:
+        streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+        outs = [l_out, tuple(torch.empty_like(x) for x in l_out)]
+
+        def step2(i):
+            with torch.cuda.stream(streams[i & 1]):
+                closest_hit(bvh, rays, out=outs[i & 1])
+        torch.cuda.synchronize()
+        for i in range(4):
+            step2(i)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        for i in range(K):
+            step2(i)
+        torch.cuda.synchronize()
+        ms2 = (time.perf_counter() - t2) * 1e3 / K
+        in_flight = {"Mrays_per_s": round(R / (ms2 * 1e-3) / 1e6, 2), "ms_per_step": round(ms2, 4),
+                     "results_equal_one_at_a_time": bool(torch.equal(outs[0][0], outs[1][0]) and
+                                                         torch.equal(outs[0][2], outs[1][2]))}
     # the optional watertight triangle test, same rays: throughput and how often its primitive differs
     prim_ref = prim.clone()
     t_ref = t.clone()
@@ -227,6 +250,7 @@ def main():
                    "triangles": N, "leaves": M, "rays_per_gpu": R, "parallelism": f"replicated-bvh x{world}"},
         "roofline": roofline,
         "hit_fraction": round(float((prim >= 0).float().mean()), 4),
+        "two_batches_in_flight": in_flight,
         "watertight_option": watertight,
     }
     if build_ms is not None:
