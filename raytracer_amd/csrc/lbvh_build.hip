@@ -550,9 +550,26 @@ inline TotalsLayout totals_layout(uint32_t capacity) {
 __device__ __forceinline__ float fold_min(float a, float b) { return (a > b) ? b : a; }
 __device__ __forceinline__ float fold_max(float a, float b) { return (a < b) ? b : a; }
 
-// start of level k (1 .. REFIT_LOG) in the compact table: level j holds REFIT_LEAVES + 1 - 2^j entries
+// The table of a window: level k (fold of 2^k leaves from every start j) in full for k = 1 .. FINE_LOG,
+// and for the levels above only at the starts that are multiples of 32 (folds of 2^(k-5) aligned blocks
+// of 32 leaves). A range of fewer than 64 leaves is two overlapping entries of a full level; a longer one
+// is its head up to a multiple of 32, its run of aligned blocks (two overlapping entries of a coarse
+// level) and its tail, folded left to right. (All ten levels in full are 74 KB of LDS, two workgroups
+// per CU; this is 50 KB, three.)
+constexpr int FINE_LOG = RADIX_LOG;
+// start of full level k (1 .. FINE_LOG): level j holds REFIT_LEAVES + 1 - 2^j entries
 __host__ __device__ constexpr int tab_off(int k) { return (k - 1) * (REFIT_LEAVES + 1) - ((1 << k) - 2); }
-constexpr int TAB_ENTRIES = tab_off(REFIT_LOG + 1);
+constexpr int TAB_ENTRIES = tab_off(FINE_LOG + 1);
+constexpr int COARSE_PER_LEVEL = REFIT_LEAVES >> RADIX_LOG; // 32 block starts
+// coarse level k (FINE_LOG .. REFIT_LOG), entry b = fold of the leaves [32 b, 32 b + 2^k)
+__host__ __device__ constexpr int coarse_off(int k) { return (k - FINE_LOG) * COARSE_PER_LEVEL; }
+constexpr int COARSE_ENTRIES = coarse_off(REFIT_LOG + 1);
+
+// A workgroup barrier for data exchanged through LDS only: waits for the workgroup's LDS operations, not
+// for its global loads, stores and atomics in flight (__syncthreads() waits for those too).
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+}
 
 __global__ __launch_bounds__(REFIT_LEAVES) void refit_window_kernel(
     const float *__restrict__ leafAABBs, const kk_lbvh_device_data *__restrict__ hdr,
@@ -560,8 +577,9 @@ __global__ __launch_bounds__(REFIT_LEAVES) void refit_window_kernel(
     TotalsLayout tl, uint32_t *__restrict__ topList, uint32_t *topCount) {
     // one thread per leaf / node; the table is built for one axis at a time, (min, max) together,
     // two levels per barrier
-    __shared__ float2 s_l0[REFIT_LEAVES]; // level 0 of the current axis
-    __shared__ float2 s_tab[TAB_ENTRIES]; // s_tab[tab_off(k) + j] = fold of leaves [j, j + 2^k)
+    __shared__ float2 s_l0[REFIT_LEAVES];        // level 0 of the current axis
+    __shared__ float2 s_tab[TAB_ENTRIES];        // s_tab[tab_off(k) + j] = fold of leaves [j, j + 2^k)
+    __shared__ float2 s_coarse[COARSE_ENTRIES];  // s_coarse[coarse_off(k) + b] = fold of leaves [32 b, 32 b + 2^k)
     const uint32_t M = hdr->compacted_face_num;
     const uint32_t b0 = blockIdx.x * REFIT_LEAVES;
     if (b0 >= M)
@@ -593,55 +611,97 @@ __global__ __launch_bounds__(REFIT_LEAVES) void refit_window_kernel(
         qlo = lo - b0;
         qhi = hi - b0;
     }
-    const int qk = inside ? 31 - __clz(static_cast<int>(qhi - qlo + 1)) : 1; // range length >= 2
+    const uint32_t qlen = inside ? qhi - qlo + 1u : 2u; // range length >= 2
+    // Nodes that cross the window's boundary go to the work list: one global atomic per workgroup, asked
+    // for now and used after the table work, so that its round trip is not waited for.
+    __shared__ uint32_t s_listed, s_listBase;
+    if (tid == 0)
+        s_listed = 0;
+    lds_barrier();
+    uint32_t slot = 0;
+    if (exists && !inside)
+        slot = atomicAdd(&s_listed, 1u);
+    lds_barrier();
+    uint32_t listBase = 0;
+    if (tid == 0 && s_listed != 0)
+        listBase = atomicAdd(topCount, s_listed);
     float2 res[3];
     const bool fullWindow = b1 - b0 == REFIT_LEAVES; // totals of a partial block are never used
     auto comb = [](float2 a, float2 b) { return make_float2(fold_min(a.x, b.x), fold_max(a.y, b.y)); };
+    // fold of the leaves [from, from + len), 1 <= len < 64, from the full levels
+    auto fine = [&](uint32_t from, uint32_t len) {
+        const int k = 31 - __clz(static_cast<int>(len));
+        const float2 *lev = k == 0 ? s_l0 : s_tab + tab_off(k);
+        return comb(lev[from], lev[from + len - (1u << k)]);
+    };
 #pragma unroll
     for (int ax = 0; ax < 3; ++ax) {
         s_l0[tid] = make_float2(mine.minPos[ax], mine.maxPos[ax]);
-        __syncthreads();
+        lds_barrier();
 #pragma unroll
-        for (int k = 1; k <= REFIT_LOG; k += 2) { // levels k and k + 1 from level k - 1
+        for (int k = 1; k <= FINE_LOG; k += 2) { // levels k and k + 1 from level k - 1
             const float2 *prev = k == 1 ? s_l0 : s_tab + tab_off(k - 1);
             const int h = 1 << (k - 1);
             if (tid + 2 * h <= REFIT_LEAVES) {
                 const float2 lo2 = comb(prev[tid], prev[tid + h]);
                 s_tab[tab_off(k) + tid] = lo2;
-                if (tid + 4 * h <= REFIT_LEAVES)
+                if (k + 1 <= FINE_LOG && tid + 4 * h <= REFIT_LEAVES)
                     s_tab[tab_off(k + 1) + tid] = comb(lo2, comb(prev[tid + 2 * h], prev[tid + 3 * h]));
             }
-            __syncthreads();
+            lds_barrier();
         }
-        if (inside)
-            res[ax] = comb(s_tab[tab_off(qk) + qlo], s_tab[tab_off(qk) + qhi + 1 - (1u << qk)]);
+        // the coarse levels, by the first 32 threads (one wave: a level's entries are written before the
+        // next level reads them)
+        if (tid < COARSE_PER_LEVEL) {
+            float2 v = s_tab[tab_off(FINE_LOG) + (tid << RADIX_LOG)];
+            s_coarse[coarse_off(FINE_LOG) + tid] = v;
+#pragma unroll
+            for (int k = FINE_LOG + 1; k <= REFIT_LOG; ++k) {
+                const int hb = 1 << (k - 1 - RADIX_LOG); // half of the level's span, in blocks
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (tid + 2 * hb <= COARSE_PER_LEVEL) {
+                    v = comb(v, s_coarse[coarse_off(k - 1) + tid + hb]);
+                    s_coarse[coarse_off(k) + tid] = v;
+                }
+            }
+        }
+        lds_barrier();
+        if (inside) {
+            if (qlen < 2u * COARSE_PER_LEVEL)
+                res[ax] = fine(qlo, qlen);
+            else {
+                const uint32_t a = (qlo + 31u) & ~31u, b = (qhi + 1u) & ~31u; // at least one block between
+                const uint32_t blocks = (b - a) >> RADIX_LOG;
+                const int km = 31 - __clz(static_cast<int>(blocks));
+                const float2 *lev = s_coarse + coarse_off(FINE_LOG + km);
+                float2 r = comb(lev[a >> RADIX_LOG], lev[(b >> RADIX_LOG) - (1u << km)]);
+                if (a != qlo)
+                    r = comb(fine(qlo, a - qlo), r);
+                if (b != qhi + 1u)
+                    r = comb(r, fine(b, qhi + 1u - b));
+                res[ax] = r;
+            }
+        }
         // aligned block totals: 32 blocks of 32 leaves and the window itself
         if (tid < 32 && (b0 + (tid + 1) * 32 <= M)) {
-            const float2 v = s_tab[tab_off(RADIX_LOG) + tid * 32];
+            const float2 v = s_coarse[coarse_off(FINE_LOG) + tid];
             float *o = totals + 6 * (tl.start[1] + (b0 >> RADIX_LOG) + tid);
             o[ax] = v.x;
             o[3 + ax] = v.y;
         }
         if (tid == 32 && fullWindow) {
-            const float2 v = s_tab[tab_off(REFIT_LOG)];
+            const float2 v = s_coarse[coarse_off(REFIT_LOG)];
             float *o = totals + 6 * (tl.start[2] + (b0 >> REFIT_LOG));
             o[ax] = v.x;
             o[3 + ax] = v.y;
         }
-        __syncthreads();
+        lds_barrier();
     }
-    // nodes that cross the window's boundary go to the work list: one global atomic per workgroup
-    __shared__ uint32_t s_listed, s_listBase;
     if (tid == 0)
-        s_listed = 0;
-    __syncthreads();
-    uint32_t slot = 0;
-    if (exists && !inside)
-        slot = atomicAdd(&s_listed, 1u);
-    __syncthreads();
-    if (tid == 0 && s_listed != 0)
-        s_listBase = atomicAdd(topCount, s_listed);
-    __syncthreads();
+        s_listBase = listBase; // (thread 0 waits for its atomic here, after the table work)
+    lds_barrier();
     if (exists) {
         if (inside) {
             float *o = nodes[i].aabb_min;
