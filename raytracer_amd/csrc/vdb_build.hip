@@ -155,14 +155,17 @@ __global__ __launch_bounds__(THREADS) void classify_kernel(const T *__restrict__
 // depth-shell voxel - "first position whose 3 x 3 window holds a non-empty voxel" - is the OR of nine
 // row masks and a count of trailing / leading zeros.
 constexpr int FILL_THREADS = 1024; // one workgroup per brick: many threads hide the latency of its loads
-template <typename T>
+// AFIX: the padded brick edge as a compile-time constant (36 = 32-voxel leaves with a two-voxel apron, the
+// layout of the reference's data sets), so that the divisions that turn a voxel index into coordinates
+// are multiplications; 0: any edge.
+template <typename T, int AFIX>
 __global__ __launch_bounds__(FILL_THREADS) void fill_atlas_lds_kernel(const T *__restrict__ vol, int dx,
                                                                  int dy, int dz,
                                                                  const kk_vdb_node *__restrict__ leaves,
                                                                  int B, int apronWid, int apronDepWid,
                                                                  Ranges<T> rngs, T *__restrict__ atlas) {
     extern __shared__ __align__(16) unsigned char s_raw[];
-    const int A = B + 2 * apronDepWid;
+    const int A = AFIX ? AFIX : B + 2 * apronDepWid;
     const int A2 = A * A;
     const size_t brickVox = static_cast<size_t>(A) * A2;
     unsigned long long *s_mask = reinterpret_cast<unsigned long long *>(s_raw); // [3][A][A]
@@ -382,11 +385,19 @@ int fillAtlas(const T *d_volume, uint32_t dx, uint32_t dy, uint32_t dz, const kk
     if (A <= 64 && p.dims[0] >= 2 && lds <= 150 * 1024) {
         // the default dynamic LDS limit is 64 KB; the attribute belongs to the current device's copy
         // of the kernel, so it is set before every launch (a cheap host-side call)
-        KK_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&fill_atlas_lds_kernel<T>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        fill_atlas_lds_kernel<T><<<plan->leaf_num, FILL_THREADS, lds, static_cast<hipStream_t>(stream)>>>(
-            d_volume, dx, dy, dz, d_node_pools + p.node_starts[0], p.dims[0], p.apron_wid,
-            p.apron_dep_wid, r, d_atlas);
+        if (A == 36) {
+            KK_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&fill_atlas_lds_kernel<T, 36>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+            fill_atlas_lds_kernel<T, 36><<<plan->leaf_num, FILL_THREADS, lds, static_cast<hipStream_t>(stream)>>>(
+                d_volume, dx, dy, dz, d_node_pools + p.node_starts[0], p.dims[0], p.apron_wid,
+                p.apron_dep_wid, r, d_atlas);
+        } else {
+            KK_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&fill_atlas_lds_kernel<T, 0>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+            fill_atlas_lds_kernel<T, 0><<<plan->leaf_num, FILL_THREADS, lds, static_cast<hipStream_t>(stream)>>>(
+                d_volume, dx, dy, dz, d_node_pools + p.node_starts[0], p.dims[0], p.apron_wid,
+                p.apron_dep_wid, r, d_atlas);
+        }
     } else
         fill_atlas_kernel<T><<<plan->leaf_num, THREADS, 0, static_cast<hipStream_t>(stream)>>>(
             d_volume, dx, dy, dz, d_node_pools + p.node_starts[0], p.dims[0], p.apron_wid,
