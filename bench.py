@@ -164,7 +164,8 @@ def main():
     # with independent ray batches would do; `value` above stays one step at a time)
     in_flight = None
     if world == 1:
-        streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+        from benchlib import two_streams
+        streams = two_streams(dev)
         outs = [l_out, tuple(torch.empty_like(x) for x in l_out)]
 
         def step2(i):

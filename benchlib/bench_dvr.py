@@ -161,7 +161,8 @@ def run(dev: str, world: int, rank: int, dist=None, frames: int = 720, warmup: i
         # as a double-buffered presentation loop would submit them. A frame ends with only its longest
         # rays still marching (one 16-row stripe alone takes a quarter of a frame's time); the next frame
         # fills the GPU meanwhile. Every frame is the one the serial loop renders.
-        streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+        from benchlib import two_streams
+        streams = two_streams(dev)
         fbs = [FrameBuffer(W, H, dev), FrameBuffer(W, H, dev)]
 
         def frame2(i):
