@@ -417,7 +417,7 @@ template <bool PARENTS>
 __global__ __launch_bounds__(KARRAS_THREADS) void karras_links_kernel(
     const uint32_t *__restrict__ mortonsGlobal, const kk_lbvh_device_data *__restrict__ hdr,
     kk_lbvh_node *__restrict__ nodes, uint32_t *__restrict__ nodeParents,
-    uint32_t *__restrict__ leafParents, uint32_t *__restrict__ rangeEnds,
+    uint32_t *__restrict__ leafParents, uint32_t *__restrict__ rangeEnds, uint2 *__restrict__ links,
     const float *__restrict__ faceBoxes, const uint32_t *__restrict__ faces,
     const uint32_t *__restrict__ compacted, float *__restrict__ leafAABBs) {
     __shared__ uint32_t s_codes[KARRAS_WIN];
@@ -481,7 +481,9 @@ __global__ __launch_bounds__(KARRAS_THREADS) void karras_links_kernel(
     if (hi == split + 1)
         rht |= LEAF;
     if (hasNode) {
-        *reinterpret_cast<uint2 *>(&nodes[i].lft) = make_uint2(lft, rht);
+        // the links go to a dense array; the refit writes each node whole, links and box together (a node's
+        // 8 bytes here and its 24 bytes there would both be partial writes of every 128-byte line)
+        links[i] = make_uint2(lft, rht);
         rangeEnds[i] = static_cast<uint32_t>(iMax); // the node covers leaves [min(i, iMax), max(i, iMax)]
     }
 
@@ -574,8 +576,8 @@ constexpr int REFIT_THREADS = 512;                      // threads of a window's
 constexpr int REFIT_PER = REFIT_LEAVES / REFIT_THREADS; // ... each with this many leaves / nodes (tid, tid + threads, ...)
 __global__ __launch_bounds__(REFIT_THREADS) void refit_window_kernel(
     const float *__restrict__ leafAABBs, const kk_lbvh_device_data *__restrict__ hdr,
-    kk_lbvh_node *nodes, const uint32_t *__restrict__ rangeEnds, float *__restrict__ totals,
-    TotalsLayout tl, uint32_t *__restrict__ topList, uint32_t *topCount) {
+    kk_lbvh_node *nodes, const uint32_t *__restrict__ rangeEnds, const uint2 *__restrict__ links,
+    float *__restrict__ totals, TotalsLayout tl, uint32_t *__restrict__ topList, uint32_t *topCount) {
     // the table is built for one axis at a time, (min, max) together, two levels per barrier.
     // (Measured at 10 M leaves: 512 threads 183 us, 1024 threads 192 us, 256 threads 248 us.)
     __shared__ float2 s_l0[REFIT_LEAVES];        // level 0 of the current axis
@@ -603,12 +605,14 @@ __global__ __launch_bounds__(REFIT_THREADS) void refit_window_kernel(
     AABB mine[REFIT_PER];
     uint32_t qlo[REFIT_PER], qlen[REFIT_PER];
     bool exists[REFIT_PER], inside[REFIT_PER];
+    uint2 link[REFIT_PER];
 #pragma unroll
     for (int e = 0; e < REFIT_PER; ++e) {
         const uint32_t i = b0 + tid + e * REFIT_THREADS;
         mine[e] = i < b1 ? load_box(leafAABBs + 6ull * i) : AABB::Initial();
         exists[e] = i < b1 && i < M - 1;
         const uint32_t other = exists[e] ? rangeEnds[i] : 0u;
+        link[e] = exists[e] ? links[i] : make_uint2(0u, 0u);
         const uint32_t lo = i < other ? i : other, hi = i < other ? other : i;
         inside[e] = exists[e] && lo >= b0 && hi < b1;
         qlo[e] = lo - b0;
@@ -720,12 +724,17 @@ __global__ __launch_bounds__(REFIT_THREADS) void refit_window_kernel(
         if (!exists[e])
             continue;
         const uint32_t i = b0 + tid + e * REFIT_THREADS;
+        // the whole node in two 16-byte stores; a node that crosses the window gets its box from refit_span
+        uint4 *o = reinterpret_cast<uint4 *>(nodes + i);
         if (inside[e]) {
-            float *o = nodes[i].aabb_min;
-            o[0] = res[e][0].x, o[1] = res[e][1].x, o[2] = res[e][2].x;
-            o[3] = res[e][0].y, o[4] = res[e][1].y, o[5] = res[e][2].y;
-        } else
+            o[0] = make_uint4(link[e].x, link[e].y, __float_as_uint(res[e][0].x), __float_as_uint(res[e][1].x));
+            o[1] = make_uint4(__float_as_uint(res[e][2].x), __float_as_uint(res[e][0].y),
+                              __float_as_uint(res[e][1].y), __float_as_uint(res[e][2].y));
+        } else {
+            o[0] = make_uint4(link[e].x, link[e].y, 0u, 0u);
+            o[1] = make_uint4(0u, 0u, 0u, 0u);
             topList[s_listBase + slot[e]] = i;
+        }
     }
 }
 
@@ -835,7 +844,7 @@ __global__ __launch_bounds__(THREADS) void refit_span_kernel(
 
 struct Ws {
     kk_lbvh_ws_layout pub;
-    size_t params, partials, keys1, vals1, faceBoxes, blockCounts, topCount, rangeEnds, topList, totals, sortWs;
+    size_t params, partials, keys1, vals1, faceBoxes, blockCounts, topCount, rangeEnds, links, topList, totals, sortWs;
     size_t sortWsBytes;
     uint32_t headBlocks;
 };
@@ -859,6 +868,7 @@ inline Ws layout(uint32_t N, uint32_t flags) {
     w.blockCounts = c.take(4 * static_cast<size_t>(w.headBlocks));
     w.topCount = c.take(4);
     w.rangeEnds = c.take(4 * n);
+    w.links = c.take(8 * n);
     w.topList = c.take(4 * n);
     w.totals = c.take(24 * totals_layout(N).boxes);
     w.sortWsBytes = kk_sort_workspace_bytes(N);
@@ -893,6 +903,7 @@ extern "C" int kk_lbvh_build(const float *d_positions, uint32_t vert_num,
                "null pointer");
     KK_REQUIRE(vert_num > 0, "no vertices");
     KK_REQUIRE(face_num > 0 && face_num <= KK_LBVH_MAX_FACES, "face_num out of range");
+    KK_REQUIRE((reinterpret_cast<uintptr_t>(d_nodes) & 15u) == 0, "d_nodes must be 16-byte aligned");
     const Ws w = layout(face_num, flags);
     if (workspace_bytes < w.pub.total_bytes) {
         set_error("LBVH workspace too small: %zu < %zu", workspace_bytes, w.pub.total_bytes);
@@ -914,6 +925,7 @@ extern "C" int kk_lbvh_build(const float *d_positions, uint32_t vert_num,
     auto *topCount = reinterpret_cast<uint32_t *>(b + w.topCount);
     auto *totals = reinterpret_cast<float *>(b + w.totals);
     auto *rangeEnds = reinterpret_cast<uint32_t *>(b + w.rangeEnds);
+    auto *links = reinterpret_cast<uint2 *>(b + w.links);
     auto *topList = reinterpret_cast<uint32_t *>(b + w.topList);
     const uint32_t N = face_num;
 
@@ -956,17 +968,17 @@ extern "C" int kk_lbvh_build(const float *d_positions, uint32_t vert_num,
     const uint32_t ngrid = div_up(N, KARRAS_THREADS);
     if (flags & KK_LBVH_KEEP_STAGES)
         karras_links_kernel<true><<<ngrid, KARRAS_THREADS, 0, stream>>>(uniq, d_out, d_nodes, nodeParents, leafParents,
-                                                                 rangeEnds, faceBoxes, d_faces, d_compacted,
+                                                                 rangeEnds, links, faceBoxes, d_faces, d_compacted,
                                                                  leafAABBs);
     else
         karras_links_kernel<false><<<ngrid, KARRAS_THREADS, 0, stream>>>(uniq, d_out, d_nodes, nodeParents, leafParents,
-                                                                  rangeEnds, faceBoxes, d_faces, d_compacted,
+                                                                  rangeEnds, links, faceBoxes, d_faces, d_compacted,
                                                                   leafAABBs);
     KK_LAUNCH_CHECK();
     KK_HIP_TRY(hipMemsetAsync(topCount, 0, 4, stream));
     const TotalsLayout tl = totals_layout(N);
     refit_window_kernel<<<div_up(N, REFIT_LEAVES), REFIT_THREADS, 0, stream>>>(
-        leafAABBs, d_out, d_nodes, rangeEnds, totals, tl, topList, topCount);
+        leafAABBs, d_out, d_nodes, rangeEnds, links, totals, tl, topList, topCount);
     KK_LAUNCH_CHECK();
     if (tl.levels >= 3) {
         block_totals_kernel<<<1, 1024, 0, stream>>>(d_out, totals, tl);
