@@ -5,7 +5,7 @@
 //   bounds_partial + build_setup : root box over ALL positions, 1/extent        (lbvh.cu:112-134)
 //   morton                      : 30-bit code of each triangle's box centre    (lbvh.cu:136-170)
 //   radix sort (radix_sort.hip) : stable sort of (code, face)                  (lbvh.cu:110,172)
-//   count_heads/scan/compact    : run starts of equal codes -> leaves          (algorithm.h:11-41)
+//   heads                       : run starts of equal codes -> leaves          (algorithm.h:11-41)
 //   karras_links                : children of each internal node (+ parents)   (lbvh.cu:29-98,221-260)
 //                                 and, in the same threads, one box per run      (lbvh.cu:186-219)
 //   refit_window/block_totals/  : node boxes as in-order folds over each node's leaf range (no
@@ -25,8 +25,6 @@ namespace lbvh {
 constexpr int THREADS = 256;
 constexpr uint32_t LEAF = 0x80000000u;
 constexpr int BOUNDS_MAX_BLOCKS = 2048;
-constexpr int HEADS_PER_THREAD = 4;
-constexpr int HEADS_PER_BLOCK = THREADS * HEADS_PER_THREAD;
 
 // Device-resident parameters produced by build_setup and read by morton.
 struct BuildParams {
@@ -100,9 +98,15 @@ __global__ __launch_bounds__(THREADS) void bounds_partial_kernel(const float *__
 // One block: reduce the partials, write the root box, 1/extent (lbvh.cu:130-134) and the header.
 __global__ __launch_bounds__(THREADS) void build_setup_kernel(
     const float *__restrict__ partials, uint32_t partialNum, uint32_t faceNum, uint32_t *faces,
-    uint32_t *compacted, kk_lbvh_node *nodes, BuildParams *params, kk_lbvh_device_data *out) {
+    uint32_t *compacted, kk_lbvh_node *nodes, BuildParams *params, kk_lbvh_device_data *out,
+    uint32_t *headStatus, uint32_t headTiles, uint32_t *topCount) {
     __shared__ float s_red[THREADS / 64][6];
     const int tid = threadIdx.x;
+    // words that later kernels of the build count in or poll start at zero
+    for (uint32_t i = tid; i < headTiles; i += THREADS)
+        headStatus[i] = 0u;
+    if (tid == 0)
+        *topCount = 0u;
     float mn[3] = {FloatMax, FloatMax, FloatMax};
     float mx[3] = {FloatMin, FloatMin, FloatMin};
     for (uint32_t b = tid; b < partialNum; b += THREADS) {
@@ -216,26 +220,16 @@ __global__ __launch_bounds__(THREADS) void morton_kernel(const float *__restrict
     rsort::hist_flush<4>(s_hist, ghist, threadIdx.x, THREADS);
 }
 
-// ---- run heads: flag[i] = (i == 0) || key[i-1] != key[i]  (include/cuda/algorithm.h:11-21) ----------
-
-__device__ __forceinline__ uint32_t load_heads(const uint32_t *__restrict__ keys, uint32_t n,
-                                               uint32_t first, uint32_t k[HEADS_PER_THREAD]) {
-    // returns a bit mask of the heads among keys[first .. first+3]
-    uint32_t prev = first == 0 ? 0u : (first < n ? keys[first - 1] : 0u);
-    uint32_t mask = 0;
-#pragma unroll
-    for (int j = 0; j < HEADS_PER_THREAD; ++j) {
-        const uint32_t i = first + j;
-        if (i < n) {
-            k[j] = keys[i];
-            if (i == 0 || k[j] != prev)
-                mask |= 1u << j;
-            prev = k[j];
-        } else
-            k[j] = 0;
-    }
-    return mask;
-}
+// ---- run heads: flag[i] = (i == 0) || key[i-1] != key[i]  (include/cuda/algorithm.h:11-41) ----------
+// compacted[c] = index of the c-th head, uniq[c] = its code (lbvh.cu:202), M = their number: flags, scan
+// and compaction in one pass over the keys. A tile of HEADS_TILE keys counts its heads, publishes the
+// count, adds up the counts of the tiles in front (a wave reads 64 of their status words per round trip
+// and stops at the first that already holds an inclusive count) and writes its heads. A tile is its
+// workgroup's index, as in the sort (radix_sort.hip): workgroups start in index order.
+constexpr int HEADS_ITEMS = 16;
+constexpr int HEADS_TILE = THREADS * HEADS_ITEMS;
+constexpr uint32_t HEADS_AGG = 1u << 30, HEADS_INC = 2u << 30, HEADS_FLAGS = 3u << 30, HEADS_VALUE = ~HEADS_FLAGS;
+constexpr uint32_t HEADS_SPIN_LIMIT = 1u << 22;
 
 __device__ __forceinline__ uint32_t wave_inclusive_scan_u32(uint32_t v, int lane) {
 #pragma unroll
@@ -247,79 +241,114 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan_u32(uint32_t v, int lane
     return v;
 }
 
-__global__ __launch_bounds__(THREADS) void count_heads_kernel(const uint32_t *__restrict__ keys,
-                                                              uint32_t n,
-                                                              uint32_t *__restrict__ blockCounts) {
+__global__ __launch_bounds__(THREADS) void heads_kernel(const uint32_t *__restrict__ keys, uint32_t n,
+                                                        uint32_t *tileStatus, uint32_t *__restrict__ compacted,
+                                                        uint32_t *__restrict__ uniq, kk_lbvh_device_data *out,
+                                                        uint32_t *errorFlag) {
     __shared__ uint32_t s_w[THREADS / 64];
-    const int tid = threadIdx.x;
-    uint32_t k[HEADS_PER_THREAD];
-    const uint32_t first = (blockIdx.x * THREADS + tid) * HEADS_PER_THREAD;
-    uint32_t cnt = __popc(load_heads(keys, n, first, k));
+    __shared__ uint32_t s_base;
+    __shared__ uint32_t s_index[HEADS_TILE], s_code[HEADS_TILE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t tile = blockIdx.x;
+    // thread t owns the keys [first, first + HEADS_ITEMS)
+    const uint32_t first = tile * HEADS_TILE + tid * HEADS_ITEMS;
+    uint32_t k[HEADS_ITEMS];
+    if (first + HEADS_ITEMS <= n) {
+        const uint4 *p = reinterpret_cast<const uint4 *>(keys + first);
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
-        cnt += __shfl_xor(cnt, o, 64);
-    if ((tid & 63) == 0)
-        s_w[tid >> 6] = cnt;
-    __syncthreads();
-    if (tid == 0)
-        blockCounts[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
-}
-
-// One block: exclusive scan of the block counts in place; the total is M (algorithm.h:27-28).
-__global__ __launch_bounds__(1024) void scan_block_counts_kernel(uint32_t *blockCounts,
-                                                                 uint32_t blockNum,
-                                                                 kk_lbvh_device_data *out) {
-    __shared__ uint32_t s_w[16];
-    __shared__ uint32_t s_carry;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0)
-        s_carry = 0;
-    __syncthreads();
-    for (uint32_t base = 0; base < blockNum; base += 1024) {
-        const uint32_t i = base + tid;
-        const uint32_t v = i < blockNum ? blockCounts[i] : 0u;
-        uint32_t incl = wave_inclusive_scan_u32(v, lane);
-        if (lane == 63)
-            s_w[wave] = incl;
-        __syncthreads();
-        uint32_t prefix = s_carry;
-        for (int w = 0; w < wave; ++w)
-            prefix += s_w[w];
-        if (i < blockNum)
-            blockCounts[i] = prefix + incl - v;
-        __syncthreads();
-        if (tid == 1023)
-            s_carry = prefix + incl;
-        __syncthreads();
+        for (int j = 0; j < HEADS_ITEMS / 4; ++j) {
+            const uint4 v = p[j];
+            k[4 * j] = v.x, k[4 * j + 1] = v.y, k[4 * j + 2] = v.z, k[4 * j + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < HEADS_ITEMS; ++j)
+            k[j] = first + j < n ? keys[first + j] : 0u;
     }
-    if (tid == 0)
-        out->compacted_face_num = s_carry;
-}
-
-// compacted[c] = index of the c-th head (algorithm.h:31-39); uniq[c] = its code (lbvh.cu:202).
-__global__ __launch_bounds__(THREADS) void compact_heads_kernel(
-    const uint32_t *__restrict__ keys, uint32_t n, const uint32_t *__restrict__ blockOffsets,
-    uint32_t *__restrict__ compacted, uint32_t *__restrict__ uniq) {
-    __shared__ uint32_t s_w[THREADS / 64];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    uint32_t k[HEADS_PER_THREAD];
-    const uint32_t first = (blockIdx.x * THREADS + tid) * HEADS_PER_THREAD;
-    const uint32_t mask = load_heads(keys, n, first, k);
+    uint32_t prev = (first != 0 && first < n) ? keys[first - 1] : 0u;
+    uint32_t mask = 0;
+#pragma unroll
+    for (int j = 0; j < HEADS_ITEMS; ++j) {
+        const uint32_t i = first + j;
+        if (i < n && (i == 0 || k[j] != prev))
+            mask |= 1u << j;
+        prev = k[j];
+    }
     const uint32_t cnt = __popc(mask);
     const uint32_t incl = wave_inclusive_scan_u32(cnt, lane);
     if (lane == 63)
         s_w[wave] = incl;
     __syncthreads();
-    uint32_t c = blockOffsets[blockIdx.x] + incl - cnt;
-    for (int w = 0; w < wave; ++w)
-        c += s_w[w];
+    uint32_t within = incl - cnt, total = 0;
 #pragma unroll
-    for (int j = 0; j < HEADS_PER_THREAD; ++j)
+    for (int w = 0; w < THREADS / 64; ++w) {
+        if (w < wave)
+            within += s_w[w];
+        total += s_w[w];
+    }
+    if (wave == 0) {
+        if (lane == 0)
+            __hip_atomic_store(tileStatus + tile, total | (tile == 0 ? HEADS_INC : HEADS_AGG), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t before = 0, t = tile, spins = 0; // the tiles t - 1, t - 2, ... 0 are still to be added
+        bool done = tile == 0;
+        while (!done) {
+            const bool there = static_cast<uint32_t>(lane) < t; // lane l looks at tile t - 1 - l
+            const uint32_t s = there ? __hip_atomic_load(tileStatus + (t - 1u - lane), __ATOMIC_RELAXED,
+                                                         __HIP_MEMORY_SCOPE_AGENT)
+                                     : 0u;
+            const uint32_t f = s & HEADS_FLAGS;
+            const unsigned long long notYet = __ballot(there && f == 0u);
+            const unsigned long long inclusive = __ballot(there && f == HEADS_INC);
+            const int firstNot = notYet ? __ffsll(static_cast<long long>(notYet)) - 1 : 64;
+            const int firstInc = inclusive ? __ffsll(static_cast<long long>(inclusive)) - 1 : 64;
+            const int left = t < 64u ? static_cast<int>(t) : 64;
+            int take = firstNot < firstInc + 1 ? firstNot : firstInc + 1; // words usable this round: lanes [0, take)
+            take = take < left ? take : left;
+            uint32_t v = lane < take ? (s & HEADS_VALUE) : 0u;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1)
+                v += __shfl_xor(v, o, 64);
+            before += v;
+            if ((firstInc < 64 && take == firstInc + 1) || static_cast<uint32_t>(take) == t)
+                done = true;
+            else {
+                if (take == 0) {
+                    if (++spins > HEADS_SPIN_LIMIT) {
+                        if (lane == 0)
+                            atomicOr(errorFlag, 1u);
+                        done = true;
+                    } else
+                        __builtin_amdgcn_s_sleep(2);
+                }
+                t -= static_cast<uint32_t>(take);
+            }
+        }
+        if (lane == 0) {
+            if (tile != 0)
+                __hip_atomic_store(tileStatus + tile, ((before + total) & HEADS_VALUE) | HEADS_INC, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            s_base = before;
+            if (tile == gridDim.x - 1)
+                out->compacted_face_num = before + total; // M (algorithm.h:27-28)
+        }
+    }
+    // the tile's heads, in order, through LDS: a thread's own heads are up to HEADS_ITEMS words apart from
+    // its neighbour's, and stores of single words scattered like that cost a sector each
+    uint32_t c = within;
+#pragma unroll
+    for (int j = 0; j < HEADS_ITEMS; ++j)
         if (mask & (1u << j)) {
-            compacted[c] = first + j;
-            uniq[c] = k[j];
+            s_index[c] = first + j;
+            s_code[c] = k[j];
             ++c;
         }
+    __syncthreads();
+    const uint32_t base = s_base;
+    for (uint32_t e = tid; e < total; e += THREADS) {
+        compacted[base + e] = s_index[e];
+        uniq[base + e] = s_code[e];
+    }
 }
 
 // lbvh.cu:221-232: length of the common leading-zero run of code[i] ^ code[j], -1 out of range.
@@ -853,7 +882,7 @@ inline Ws layout(uint32_t N, uint32_t flags) {
     Ws w;
     Carver c;
     const size_t n = N;
-    w.headBlocks = div_up(N, HEADS_PER_BLOCK);
+    w.headBlocks = div_up(N, HEADS_TILE);
     w.params = c.take(sizeof(BuildParams));
     w.partials = c.take(sizeof(float) * 6 * BOUNDS_MAX_BLOCKS);
     w.pub.sorted_mortons = c.take(4 * n); // keys0: Morton codes, sorted in place by the 4 passes
@@ -935,7 +964,7 @@ extern "C" int kk_lbvh_build(const float *d_positions, uint32_t vert_num,
     bounds_partial_kernel<<<bgrid, THREADS, 0, stream>>>(d_positions, vert_num, partials);
     KK_LAUNCH_CHECK();
     build_setup_kernel<<<1, THREADS, 0, stream>>>(partials, bgrid, N, d_faces, d_compacted, d_nodes,
-                                                  params, d_out);
+                                                  params, d_out, blockCounts, w.headBlocks, topCount);
     KK_LAUNCH_CHECK();
     uint32_t *ghist = nullptr;
     int rc = rsort::sort_prepare(b + w.sortWs, w.sortWsBytes, N, stream, &ghist);
@@ -957,12 +986,8 @@ extern "C" int kk_lbvh_build(const float *d_positions, uint32_t vert_num,
     if (rc != KK_OK)
         return rc;
 
-    count_heads_kernel<<<w.headBlocks, THREADS, 0, stream>>>(keys0, N, blockCounts);
-    KK_LAUNCH_CHECK();
-    scan_block_counts_kernel<<<1, 1024, 0, stream>>>(blockCounts, w.headBlocks, d_out);
-    KK_LAUNCH_CHECK();
-    compact_heads_kernel<<<w.headBlocks, THREADS, 0, stream>>>(keys0, N, blockCounts, d_compacted,
-                                                               uniq);
+    heads_kernel<<<w.headBlocks, THREADS, 0, stream>>>(keys0, N, blockCounts, d_compacted, uniq, d_out,
+                                                       reinterpret_cast<uint32_t *>(b + w.pub.error_flag));
     KK_LAUNCH_CHECK();
 
     const uint32_t ngrid = div_up(N, KARRAS_THREADS);
@@ -975,7 +1000,6 @@ extern "C" int kk_lbvh_build(const float *d_positions, uint32_t vert_num,
                                                                   rangeEnds, links, faceBoxes, d_faces, d_compacted,
                                                                   leafAABBs);
     KK_LAUNCH_CHECK();
-    KK_HIP_TRY(hipMemsetAsync(topCount, 0, 4, stream));
     const TotalsLayout tl = totals_layout(N);
     refit_window_kernel<<<div_up(N, REFIT_LEAVES), REFIT_THREADS, 0, stream>>>(
         leafAABBs, d_out, d_nodes, rangeEnds, links, totals, tl, topList, topCount);
