@@ -873,16 +873,16 @@ __global__ __launch_bounds__(THREADS) void refit_span_kernel(
 
 struct Ws {
     kk_lbvh_ws_layout pub;
-    size_t params, partials, keys1, vals1, faceBoxes, blockCounts, topCount, rangeEnds, links, topList, totals, sortWs;
+    size_t params, partials, keys1, vals1, faceBoxes, headStatus, topCount, rangeEnds, links, topList, totals, sortWs;
     size_t sortWsBytes;
-    uint32_t headBlocks;
+    uint32_t headTiles;
 };
 
 inline Ws layout(uint32_t N, uint32_t flags) {
     Ws w;
     Carver c;
     const size_t n = N;
-    w.headBlocks = div_up(N, HEADS_TILE);
+    w.headTiles = div_up(N, HEADS_TILE);
     w.params = c.take(sizeof(BuildParams));
     w.partials = c.take(sizeof(float) * 6 * BOUNDS_MAX_BLOCKS);
     w.pub.sorted_mortons = c.take(4 * n); // keys0: Morton codes, sorted in place by the 4 passes
@@ -894,7 +894,7 @@ inline Ws layout(uint32_t N, uint32_t flags) {
     w.pub.leaf_aabbs = c.take(24 * n);
     w.pub.node_parents = c.take(4 * n);
     w.pub.leaf_parents = c.take(4 * n);
-    w.blockCounts = c.take(4 * static_cast<size_t>(w.headBlocks));
+    w.headStatus = c.take(4 * static_cast<size_t>(w.headTiles));
     w.topCount = c.take(4);
     w.rangeEnds = c.take(4 * n);
     w.links = c.take(8 * n);
@@ -950,7 +950,7 @@ extern "C" int kk_lbvh_build(const float *d_positions, uint32_t vert_num,
     auto *leafAABBs = reinterpret_cast<float *>(b + w.pub.leaf_aabbs);
     auto *nodeParents = reinterpret_cast<uint32_t *>(b + w.pub.node_parents);
     auto *leafParents = reinterpret_cast<uint32_t *>(b + w.pub.leaf_parents);
-    auto *blockCounts = reinterpret_cast<uint32_t *>(b + w.blockCounts);
+    auto *headStatus = reinterpret_cast<uint32_t *>(b + w.headStatus);
     auto *topCount = reinterpret_cast<uint32_t *>(b + w.topCount);
     auto *totals = reinterpret_cast<float *>(b + w.totals);
     auto *rangeEnds = reinterpret_cast<uint32_t *>(b + w.rangeEnds);
@@ -964,7 +964,7 @@ extern "C" int kk_lbvh_build(const float *d_positions, uint32_t vert_num,
     bounds_partial_kernel<<<bgrid, THREADS, 0, stream>>>(d_positions, vert_num, partials);
     KK_LAUNCH_CHECK();
     build_setup_kernel<<<1, THREADS, 0, stream>>>(partials, bgrid, N, d_faces, d_compacted, d_nodes,
-                                                  params, d_out, blockCounts, w.headBlocks, topCount);
+                                                  params, d_out, headStatus, w.headTiles, topCount);
     KK_LAUNCH_CHECK();
     uint32_t *ghist = nullptr;
     int rc = rsort::sort_prepare(b + w.sortWs, w.sortWsBytes, N, stream, &ghist);
@@ -986,7 +986,7 @@ extern "C" int kk_lbvh_build(const float *d_positions, uint32_t vert_num,
     if (rc != KK_OK)
         return rc;
 
-    heads_kernel<<<w.headBlocks, THREADS, 0, stream>>>(keys0, N, blockCounts, d_compacted, uniq, d_out,
+    heads_kernel<<<w.headTiles, THREADS, 0, stream>>>(keys0, N, headStatus, d_compacted, uniq, d_out,
                                                        reinterpret_cast<uint32_t *>(b + w.pub.error_flag));
     KK_LAUNCH_CHECK();
 
