@@ -96,6 +96,31 @@ def test_build_without_stages_is_the_same_tree():
         assert ha[name].tobytes() == hb[name].tobytes(), name
 
 
+def test_builds_in_flight_on_two_streams_equal_serial_builds():
+    """The sort and the run-head compaction number their tiles by workgroup index and look back over the
+    tiles in front; two builds whose workgroups share the chip must still each see their own in order."""
+    meshes = [syn.triangle_soup(600_000), syn.triangle_soup(450_000, seed=7)]
+    serial = []
+    for pos, tri in meshes:
+        b = LBVH(DEV)
+        b.BuildFrom(pos, tri)
+        serial.append(b.to_host())
+    builders = [LBVH(DEV), LBVH(DEV)]
+    for b, (pos, tri) in zip(builders, meshes):
+        b.BuildFrom(pos, tri)  # allocates and uploads; the rebuilds below only launch
+    streams = [torch.cuda.Stream(DEV), torch.cuda.Stream(DEV)]
+    torch.cuda.synchronize()
+    for _ in range(5):
+        for b, s in zip(builders, streams):
+            with torch.cuda.stream(s):
+                b.rebuild()
+    torch.cuda.synchronize()
+    for b, want in zip(builders, serial):
+        got = b.to_host()
+        for name in ("faces", "compactedFaces", "internalNodes", "leafAABBs", "uniqueMortons"):
+            assert got[name].tobytes() == want[name].tobytes(), name
+
+
 def test_build_veach_mis(oracle, veach):
     bvh, ref = _compare_build(oracle, veach["positions"], veach["face_position_indices"])
     assert ref["M"] == 1343
