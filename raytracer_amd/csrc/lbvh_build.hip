@@ -446,7 +446,7 @@ template <bool PARENTS>
 __global__ __launch_bounds__(KARRAS_THREADS) void karras_links_kernel(
     const uint32_t *__restrict__ mortonsGlobal, const kk_lbvh_device_data *__restrict__ hdr,
     kk_lbvh_node *__restrict__ nodes, uint32_t *__restrict__ nodeParents,
-    uint32_t *__restrict__ leafParents, uint32_t *__restrict__ rangeEnds, uint2 *__restrict__ links,
+    uint32_t *__restrict__ leafParents, uint2 *__restrict__ nodeInfo,
     const float *__restrict__ faceBoxes, const uint32_t *__restrict__ faces,
     const uint32_t *__restrict__ compacted, float *__restrict__ leafAABBs) {
     __shared__ uint32_t s_codes[KARRAS_WIN];
@@ -510,10 +510,12 @@ __global__ __launch_bounds__(KARRAS_THREADS) void karras_links_kernel(
     if (hi == split + 1)
         rht |= LEAF;
     if (hasNode) {
-        // the links go to a dense array; the refit writes each node whole, links and box together (a node's
-        // 8 bytes here and its 24 bytes there would both be partial writes of every 128-byte line)
-        links[i] = make_uint2(lft, rht);
-        rangeEnds[i] = static_cast<uint32_t>(iMax); // the node covers leaves [min(i, iMax), max(i, iMax)]
+        // Links and range go to a dense array, eight bytes a node: x = the split position with the two
+        // leaf flags (the right child's index is the left one's plus one), y = the other end of the node's
+        // leaf range [min(i, iMax), max(i, iMax)]. The refit writes each node whole, links and box together
+        // (a node's 8 bytes here and its 24 bytes there would both be partial writes of every 128-byte line).
+        nodeInfo[i] = make_uint2(static_cast<uint32_t>(split) | (lft & LEAF) | ((rht & LEAF) >> 1),
+                                 static_cast<uint32_t>(iMax));
     }
 
     AABB box;
@@ -605,8 +607,7 @@ constexpr int REFIT_THREADS = 512;                      // threads of a window's
 constexpr int REFIT_PER = REFIT_LEAVES / REFIT_THREADS; // ... each with this many leaves / nodes (tid, tid + threads, ...)
 __global__ __launch_bounds__(REFIT_THREADS) void refit_window_kernel(
     const float *__restrict__ leafAABBs, const kk_lbvh_device_data *__restrict__ hdr,
-    kk_lbvh_node *nodes, const uint32_t *__restrict__ rangeEnds, const uint2 *__restrict__ links,
-    float *__restrict__ totals, TotalsLayout tl, uint32_t *__restrict__ topList, uint32_t *topCount) {
+    kk_lbvh_node *nodes, const uint2 *__restrict__ nodeInfo, float *__restrict__ totals, TotalsLayout tl, uint32_t *__restrict__ topList, uint32_t *topCount) {
     // the table is built for one axis at a time, (min, max) together, two levels per barrier.
     // (Measured at 10 M leaves: 512 threads 183 us, 1024 threads 192 us, 256 threads 248 us.)
     __shared__ float2 s_l0[REFIT_LEAVES];        // level 0 of the current axis
@@ -640,8 +641,10 @@ __global__ __launch_bounds__(REFIT_THREADS) void refit_window_kernel(
         const uint32_t i = b0 + tid + e * REFIT_THREADS;
         mine[e] = i < b1 ? load_box(leafAABBs + 6ull * i) : AABB::Initial();
         exists[e] = i < b1 && i < M - 1;
-        const uint32_t other = exists[e] ? rangeEnds[i] : 0u;
-        link[e] = exists[e] ? links[i] : make_uint2(0u, 0u);
+        const uint2 info = exists[e] ? nodeInfo[i] : make_uint2(0u, 0u);
+        const uint32_t other = info.y;
+        link[e] = make_uint2((info.x & 0x3FFFFFFFu) | (info.x & LEAF),
+                             ((info.x & 0x3FFFFFFFu) + 1u) | ((info.x << 1) & LEAF));
         const uint32_t lo = i < other ? i : other, hi = i < other ? other : i;
         inside[e] = exists[e] && lo >= b0 && hi < b1;
         qlo[e] = lo - b0;
@@ -795,7 +798,7 @@ __global__ __launch_bounds__(1024) void block_totals_kernel(
 // dependent loads; a whole wave per node spends more on finding the runs than on the fold.)
 __global__ __launch_bounds__(THREADS) void refit_span_kernel(
     const float *__restrict__ leafAABBs, const kk_lbvh_device_data *__restrict__ hdr,
-    kk_lbvh_node *nodes, const uint32_t *__restrict__ rangeEnds, const float *__restrict__ totals,
+    kk_lbvh_node *nodes, const uint2 *__restrict__ nodeInfo, const float *__restrict__ totals,
     TotalsLayout tl, const uint32_t *__restrict__ topList, const uint32_t *__restrict__ topCount) {
     constexpr int SPAN_LANES = 16, GROUPS = THREADS / SPAN_LANES;
     constexpr int MAX_RUNS = 2 * (MAX_TOTAL_LEVELS + 1);
@@ -811,7 +814,7 @@ __global__ __launch_bounds__(THREADS) void refit_span_kernel(
     // inside a group)
     for (uint32_t e = blockIdx.x * GROUPS + group; e < count; e += gridDim.x * GROUPS) {
         const uint32_t i = topList[e];
-        const uint32_t other = rangeEnds[i];
+        const uint32_t other = nodeInfo[i].y;
         uint64_t p = i < other ? i : other;                  // next leaf to take in
         const uint64_t end = (i < other ? other : i) + 1ull; // one past the range
         // the runs: level, first block of that level, number of blocks (the lanes of a group compute
@@ -873,7 +876,7 @@ __global__ __launch_bounds__(THREADS) void refit_span_kernel(
 
 struct Ws {
     kk_lbvh_ws_layout pub;
-    size_t params, partials, keys1, vals1, faceBoxes, headStatus, topCount, rangeEnds, links, topList, totals, sortWs;
+    size_t params, partials, keys1, vals1, faceBoxes, headStatus, topCount, nodeInfo, topList, totals, sortWs;
     size_t sortWsBytes;
     uint32_t headTiles;
 };
@@ -896,8 +899,7 @@ inline Ws layout(uint32_t N, uint32_t flags) {
     w.pub.leaf_parents = c.take(4 * n);
     w.headStatus = c.take(4 * static_cast<size_t>(w.headTiles));
     w.topCount = c.take(4);
-    w.rangeEnds = c.take(4 * n);
-    w.links = c.take(8 * n);
+    w.nodeInfo = c.take(8 * n);
     w.topList = c.take(4 * n);
     w.totals = c.take(24 * totals_layout(N).boxes);
     w.sortWsBytes = kk_sort_workspace_bytes(N);
@@ -953,8 +955,7 @@ extern "C" int kk_lbvh_build(const float *d_positions, uint32_t vert_num,
     auto *headStatus = reinterpret_cast<uint32_t *>(b + w.headStatus);
     auto *topCount = reinterpret_cast<uint32_t *>(b + w.topCount);
     auto *totals = reinterpret_cast<float *>(b + w.totals);
-    auto *rangeEnds = reinterpret_cast<uint32_t *>(b + w.rangeEnds);
-    auto *links = reinterpret_cast<uint2 *>(b + w.links);
+    auto *nodeInfo = reinterpret_cast<uint2 *>(b + w.nodeInfo);
     auto *topList = reinterpret_cast<uint32_t *>(b + w.topList);
     const uint32_t N = face_num;
 
@@ -993,22 +994,22 @@ extern "C" int kk_lbvh_build(const float *d_positions, uint32_t vert_num,
     const uint32_t ngrid = div_up(N, KARRAS_THREADS);
     if (flags & KK_LBVH_KEEP_STAGES)
         karras_links_kernel<true><<<ngrid, KARRAS_THREADS, 0, stream>>>(uniq, d_out, d_nodes, nodeParents, leafParents,
-                                                                 rangeEnds, links, faceBoxes, d_faces, d_compacted,
+                                                                 nodeInfo, faceBoxes, d_faces, d_compacted,
                                                                  leafAABBs);
     else
         karras_links_kernel<false><<<ngrid, KARRAS_THREADS, 0, stream>>>(uniq, d_out, d_nodes, nodeParents, leafParents,
-                                                                  rangeEnds, links, faceBoxes, d_faces, d_compacted,
+                                                                  nodeInfo, faceBoxes, d_faces, d_compacted,
                                                                   leafAABBs);
     KK_LAUNCH_CHECK();
     const TotalsLayout tl = totals_layout(N);
     refit_window_kernel<<<div_up(N, REFIT_LEAVES), REFIT_THREADS, 0, stream>>>(
-        leafAABBs, d_out, d_nodes, rangeEnds, links, totals, tl, topList, topCount);
+        leafAABBs, d_out, d_nodes, nodeInfo, totals, tl, topList, topCount);
     KK_LAUNCH_CHECK();
     if (tl.levels >= 3) {
         block_totals_kernel<<<1, 1024, 0, stream>>>(d_out, totals, tl);
         KK_LAUNCH_CHECK();
     }
-    refit_span_kernel<<<REFIT_SPAN_BLOCKS, THREADS, 0, stream>>>(leafAABBs, d_out, d_nodes, rangeEnds,
+    refit_span_kernel<<<REFIT_SPAN_BLOCKS, THREADS, 0, stream>>>(leafAABBs, d_out, d_nodes, nodeInfo,
                                                                  totals, tl, topList, topCount);
     KK_LAUNCH_CHECK();
     return KK_OK;
