@@ -106,7 +106,7 @@ int kk_lbvh_workspace_layout(uint32_t face_num, uint32_t vert_num, uint32_t flag
  *   d_face_pos_idx   uint32[face_num][3]
  *   d_faces          uint32[face_num]        out
  *   d_compacted      uint32[face_num]        out (M used)
- *   d_nodes          kk_lbvh_node[face_num]  out (max(M-1,1) used)
+ *   d_nodes          kk_lbvh_node[face_num]  out (max(M-1,1) used), 16-byte aligned
  *   d_out            kk_lbvh_device_data     out; its pointers are set to the three arrays above
  * When M == 1 the reference allocates no internal node yet its traversal reads node 0; here node 0 is
  * then written with both children = leaf 0 and the leaf's box. face_num == 0 is rejected. */
