@@ -313,6 +313,7 @@ def main():
     if dvr:
         out["dvr"] = dvr
         out["dvr_fps_4k"] = dvr["fps"]
+        out["dvr_fps_4k_launch_order"] = dvr.get("fps_launch_order")
         out["dvr_fps_4k_two_frames_in_flight"] = dvr.get("fps_two_frames_in_flight")
     if dvr_head:
         out["dvr_head_1080p"] = dvr_head

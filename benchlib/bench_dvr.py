@@ -79,6 +79,10 @@ def run(dev: str, world: int, rank: int, dist=None, frames: int = 720, warmup: i
         c.Revolve(cam._c("sqrtf", cam._dot(c.pos, c.pos)), 0.5, 0.0)
         poses.append((c.pos.copy(), c.rotation().copy()))
     fb = FrameBuffer(W, H, dev)
+    # One GPU renders whole frames and starts each frame's tiles in the order of what they took in the
+    # frame before (the sort of the tile times is inside the timed loop); the same loop in plain launch
+    # order is timed beside it. Several GPUs render interleaved stripes, which are launched as they are.
+    caster.SetAdaptiveTileOrder(world == 1)
     gatherer = None
     if world > 1:
         from raytracer_amd.multi_gpu import StripeGatherer
@@ -157,6 +161,18 @@ def run(dev: str, world: int, rank: int, dist=None, frames: int = 720, warmup: i
         out["gathered_frame_equals_single_gpu"] = same_frame
         out["transport"] = "kk_comm (library RCCL)" if comm is not None else f"torch.distributed/{dist.get_backend()}"
     if world == 1:
+        adaptive_last = fb.rgba.clone()
+        caster.SetAdaptiveTileOrder(False)
+        for i in range(warmup):
+            frame(i)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(warmup, warmup + frames):
+            frame(i)
+        torch.cuda.synchronize()
+        out["fps_launch_order"] = round(frames / (time.perf_counter() - t1), 2)
+        out["adaptive_order_last_frame_equals_launch_order"] = bool(torch.equal(adaptive_last, fb.rgba))
+        del adaptive_last
         # Two frames in flight: the orbit's frames alternate over two HIP streams and two frame buffers,
         # as a double-buffered presentation loop would submit them. A frame ends with only its longest
         # rays still marching (one 16-row stripe alone takes a quarter of a frame's time); the next frame

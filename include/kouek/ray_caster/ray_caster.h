@@ -99,11 +99,39 @@ class RayCaster : Noncopyable {
             std::cerr << ErrTag << " at " << __FILE__ << ":" << __LINE__ << ". vdb or tfTex are not set.\n";
             return;
         }
+        void *s = stream ? stream->Get() : nullptr;
+        if (adaptiveTileOrder && rndrTarget == DPBXVDBRenderTarget::Scene && rndrSz.x > 0 && rndrSz.y > 0) {
+            const uint32_t tiles = kk_dvr_tile_count(rndrSz.x, rndrSz.y);
+            if (tiles != tileCost.size()) {
+                haveTileOrder = false;
+                if (!tileCost.resize(tiles) || !tileOrder.resize(tiles) ||
+                    !tileOrderWs.resize(kk_dvr_tile_order_workspace_bytes(tiles)))
+                    return;
+            }
+            auto ordered = sizeof(T) == 1 ? kk_dvr_render_ordered_u8 : kk_dvr_render_ordered_u16;
+            if (KOUEK_HIP_CHECK(ErrTag.data(),
+                                ordered(&vdb->GetDeviceData(), tfTex->Get(), &rndrParam, &rndrParamPerFrame,
+                                        rndrTo.Get(), rndrSz.x, rndrSz.y, 0, rndrSz.y, tileCost.data(),
+                                        haveTileOrder ? tileOrder.data() : nullptr, s)))
+                haveTileOrder = KOUEK_HIP_CHECK(ErrTag.data(),
+                                                kk_dvr_tile_order(tileCost.data(), tiles, tileOrder.data(),
+                                                                  tileOrderWs.data(), tileOrderWs.size(), s));
+            return;
+        }
         auto fn = sizeof(T) == 1 ? kk_dvr_render_target_u8 : kk_dvr_render_target_u16;
         KOUEK_HIP_CHECK(ErrTag.data(),
                         fn(&vdb->GetDeviceData(), tfTex->Get(), &rndrParam, &rndrParamPerFrame,
                            static_cast<int>(rndrTarget), displayLev, displayLeafLayer, rndrTo.Get(), rndrSz.x,
-                           rndrSz.y, 0, rndrSz.y, stream ? stream->Get() : nullptr));
+                           rndrSz.y, 0, rndrSz.y, s));
+    }
+    // Start each Scene frame's 16 x 16 tiles in the order of what they took in the frame before, the
+    // costly ones first: the same image, a shorter frame, since the longest rays no longer start last.
+    // Not part of the reference, whose launch order is the tiles' own
+    // (src/ray_caster/ray_caster_dpbx_vdb.cu:1027-1034). The state is this object's: frames in flight on
+    // several streams take a RayCaster each.
+    void SetAdaptiveTileOrder(bool on) {
+        adaptiveTileOrder = on;
+        haveTileOrder = false;
     }
 
     // Several GPUs (not part of the reference): every rank of `comm` renders its round-robin 16-row
@@ -136,7 +164,9 @@ class RayCaster : Noncopyable {
     }
 
   private:
-    HIP::DeviceBuffer<uint8_t> stripeSend, stripeBlocks;
+    HIP::DeviceBuffer<uint8_t> stripeSend, stripeBlocks, tileOrderWs;
+    HIP::DeviceBuffer<uint32_t> tileCost, tileOrder;
+    bool adaptiveTileOrder = false, haveTileOrder = false;
 };
 
 } // namespace RayCaster

@@ -470,6 +470,26 @@ int kk_dvr_render_u16(const kk_vdb_device_data *h_vdb, const float *d_tf,
                       const kk_dvr_params *h_params, const kk_dvr_frame *h_frame, uint8_t *d_rgba,
                       int width, int height, int y0, int y1, unsigned long long *d_counters,
                       void *stream);
+/* The same frame with its 16 x 16 pixel tiles started in a given order, and what each tile took reported
+ * back: the frame time of a marcher is set by where its longest rays are started, and an interactive
+ * renderer knows that from the frame before. Tiles are numbered row by row over the rendered rows
+ * (kk_dvr_tile_count(width, y1 - y0) of them). d_tile_order (optional): a permutation of the tile numbers,
+ * workgroup n renders tile d_tile_order[n]. d_tile_cost (optional): uint32 per tile, the time the tile's
+ * workgroup took, in units of 64 clock cycles, capped at 65535. kk_dvr_tile_order sorts the tiles by cost,
+ * the costly ones first (ties by tile number), into d_tile_order. The image does not depend on the order.
+ * No counterpart in the reference, whose launch order is the tiles' own. The buffers belong to one
+ * sequence of frames: frames in flight on different streams need a set each. */
+uint32_t kk_dvr_tile_count(int width, int rows);
+int kk_dvr_render_ordered_u8(const kk_vdb_device_data *h_vdb, const float *d_tf, const kk_dvr_params *h_params,
+                             const kk_dvr_frame *h_frame, uint8_t *d_rgba, int width, int height, int y0,
+                             int y1, uint32_t *d_tile_cost, const uint32_t *d_tile_order, void *stream);
+int kk_dvr_render_ordered_u16(const kk_vdb_device_data *h_vdb, const float *d_tf,
+                              const kk_dvr_params *h_params, const kk_dvr_frame *h_frame, uint8_t *d_rgba,
+                              int width, int height, int y0, int y1, uint32_t *d_tile_cost,
+                              const uint32_t *d_tile_order, void *stream);
+size_t kk_dvr_tile_order_workspace_bytes(uint32_t tiles);
+int kk_dvr_tile_order(const uint32_t *d_tile_cost, uint32_t tiles, uint32_t *d_tile_order, void *d_workspace,
+                      size_t workspace_bytes, void *stream);
 /* The same frame restricted to the 16-row stripes stripe_first, stripe_first + stripe_stride, ... of
  * the image (stripe s = rows [16 s, 16 s + 16)): the share of one GPU when the image is dealt out to
  * several in round-robin stripes. No counterpart in the reference, which renders on one GPU. */

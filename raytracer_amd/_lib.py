@@ -128,6 +128,12 @@ def _declare(l):
         getattr(l, f"kk_dvr_render_target_{sfx}").argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, i32, i32, i32, i32, vp]
     for sfx in ("u8", "u16"):
         getattr(l, f"kk_dvr_render_stripes_compact_{sfx}").argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]
+        getattr(l, f"kk_dvr_render_ordered_{sfx}").argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp]
+    l.kk_dvr_tile_count.restype = u32
+    l.kk_dvr_tile_count.argtypes = [i32, i32]
+    l.kk_dvr_tile_order_workspace_bytes.restype = sz
+    l.kk_dvr_tile_order_workspace_bytes.argtypes = [u32]
+    l.kk_dvr_tile_order.argtypes = [vp, u32, vp, vp, sz, vp]
     l.kk_comm_unique_id.argtypes = [vp]
     l.kk_comm_init.argtypes = [i32, i32, vp, C.POINTER(vp)]
     l.kk_comm_destroy.argtypes = [vp]

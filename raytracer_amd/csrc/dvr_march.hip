@@ -14,6 +14,9 @@
 //   * the 256-entry transfer function sits in LDS; lookup x = u * 256 - 0.5, linear, 0 outside.
 #include "kk_host.h"
 #include "kk_math.h"
+#include "radix_hist.h"
+
+extern "C" size_t kk_sort_workspace_bytes(uint32_t n);
 
 namespace kk {
 namespace dvr {
@@ -219,7 +222,17 @@ __global__ __launch_bounds__(THREADS) void dvr_kernel(const kk_vdb_device_data v
                                                       const kk_dvr_params rp, const kk_dvr_frame fr,
                                                       uint8_t *__restrict__ rgba, int W, int H, int y0,
                                                       int y1, int stripeFirst, int stripeStride,
-                                                      int compact, unsigned long long *counters) {
+                                                      int compact, unsigned long long *counters,
+                                                      uint32_t *__restrict__ tileCost,
+                                                      const uint32_t *__restrict__ tileOrder) {
+    // Which 16 x 16 pixel tile this workgroup renders: its own index, or the entry of `tileOrder` there
+    // (a permutation of the launch's tiles, the costly ones first). What a tile took goes to `tileCost`
+    // for the order of the next frame. Both optional; the image does not depend on them.
+    const long long tileStart = (tileCost != nullptr) ? clock64() : 0ll;
+    uint32_t tileId = blockIdx.y * gridDim.x + blockIdx.x;
+    if (tileOrder != nullptr) // an entry that is no tile of this launch must not become an address
+        tileId = min(tileOrder[tileId], gridDim.x * gridDim.y - 1u);
+    const uint32_t tileX = tileId % gridDim.x, tileY = tileId / gridDim.x;
     __shared__ float4 s_tf[TF_LDS];
     __shared__ float s_norm[256];
     const int tid = threadIdx.x;
@@ -230,9 +243,9 @@ __global__ __launch_bounds__(THREADS) void dvr_kernel(const kk_vdb_device_data v
 
     // 16 x 16 pixel block = 2 x 2 waves of 8 x 8 pixels
     const int lane = tid & 63, wave = tid >> 6;
-    const int x = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
-    // block row blockIdx.y renders the 16-row stripe number stripeFirst + blockIdx.y * stripeStride
-    const int y = y0 + (stripeFirst + static_cast<int>(blockIdx.y) * stripeStride) * 16 + (wave >> 1) * 8 +
+    const int x = static_cast<int>(tileX) * 16 + (wave & 1) * 8 + (lane & 7);
+    // tile row tileY renders the 16-row stripe number stripeFirst + tileY * stripeStride
+    const int y = y0 + (stripeFirst + static_cast<int>(tileY) * stripeStride) * 16 + (wave >> 1) * 8 +
                   (lane >> 3);
     unsigned long long nSamples = 0, nBricks = 0;
     const bool inside = x < W && y < y1;
@@ -559,7 +572,7 @@ __global__ __launch_bounds__(THREADS) void dvr_kernel(const kk_vdb_device_data v
             o.w = static_cast<uint8_t>(255.f * a);
         }
         // compact: this launch's stripes one after the other (the block a rank sends to the gatherer)
-        const int outRow = compact ? static_cast<int>(blockIdx.y) * 16 + (wave >> 1) * 8 + (lane >> 3) : y;
+        const int outRow = compact ? static_cast<int>(tileY) * 16 + (wave >> 1) * 8 + (lane >> 3) : y;
         reinterpret_cast<uchar4 *>(rgba)[static_cast<size_t>(outRow) * W + x] = o;
     }
 
@@ -572,6 +585,10 @@ __global__ __launch_bounds__(THREADS) void dvr_kernel(const kk_vdb_device_data v
             atomicAdd(&counters[0], nSamples);
             atomicAdd(&counters[1], nBricks);
         }
+    }
+    if (tileCost != nullptr && tid == 0) { // in units of 64 cycles, so that any frame's tiles fit 16 bits
+        const long long took = (clock64() - tileStart) >> 6;
+        tileCost[tileId] = took > 65535ll ? 65535u : static_cast<uint32_t>(took);
     }
 }
 
@@ -994,7 +1011,7 @@ template <typename T>
 int launch(const kk_vdb_device_data *h_vdb, const float *d_tf, const kk_dvr_params *h_params,
            const kk_dvr_frame *h_frame, uint8_t *d_rgba, int width, int height, int y0, int y1,
            int stripeFirst, int stripeStride, unsigned long long *d_counters, hipStream_t stream,
-           int compact = 0) {
+           int compact = 0, uint32_t *d_tile_cost = nullptr, const uint32_t *d_tile_order = nullptr) {
     KK_REQUIRE(h_vdb && d_tf && h_params && h_frame && d_rgba, "null pointer");
     KK_REQUIRE(h_vdb->node_pools && h_vdb->child_pools && h_vdb->atlas, "VDB arrays missing");
     KK_REQUIRE(h_vdb->voxel_bytes == sizeof(T), "voxel type does not match the VDB");
@@ -1016,7 +1033,7 @@ int launch(const kk_vdb_device_data *h_vdb, const float *d_tf, const kk_dvr_para
 #define KK_LAUNCH_DVR(COUNT, SHADING, AFIX)                                                        \
     dvr_kernel<T, COUNT, SHADING, AFIX><<<grid, THREADS, 0, stream>>>(                             \
         *h_vdb, d_tf, *h_params, *h_frame, d_rgba, width, height, y0, y1, stripeFirst, stripeStride, compact, \
-        d_counters)
+        d_counters, d_tile_cost, d_tile_order)
     const bool shading = h_params->use_shading != 0;
     const bool edge36 = h_vdb->vdb_param.vox_per_atlas_brick == 36;
     if (d_counters) {
@@ -1040,8 +1057,68 @@ int launch(const kk_vdb_device_data *h_vdb, const float *d_tf, const kk_dvr_para
     return KK_OK;
 }
 
+// keys for the sort that puts the costly tiles first: the cost, complemented
+__global__ __launch_bounds__(THREADS) void tile_keys_kernel(const uint32_t *__restrict__ cost, uint32_t n,
+                                                            uint32_t *__restrict__ keys) {
+    const uint32_t i = blockIdx.x * THREADS + threadIdx.x;
+    if (i < n)
+        keys[i] = 65535u - (cost[i] > 65535u ? 65535u : cost[i]);
+}
+
+struct OrderWs {
+    size_t keysA, keysB, valsB, sortWs, sortWsBytes, total;
+};
+inline OrderWs order_ws(uint32_t tiles) {
+    OrderWs w;
+    Carver c;
+    w.keysA = c.take(4 * static_cast<size_t>(tiles));
+    w.keysB = c.take(4 * static_cast<size_t>(tiles));
+    w.valsB = c.take(4 * static_cast<size_t>(tiles));
+    w.sortWsBytes = kk_sort_workspace_bytes(tiles);
+    w.sortWs = c.take(w.sortWsBytes);
+    w.total = c.off;
+    return w;
+}
+
 } // namespace dvr
 } // namespace kk
+
+extern "C" uint32_t kk_dvr_tile_count(int width, int rows) {
+    return width > 0 && rows > 0 ? kk::div_up(width, 16) * kk::div_up(rows, 16) : 0u;
+}
+extern "C" size_t kk_dvr_tile_order_workspace_bytes(uint32_t tiles) { return kk::dvr::order_ws(tiles).total; }
+extern "C" int kk_dvr_tile_order(const uint32_t *d_tile_cost, uint32_t tiles, uint32_t *d_tile_order,
+                                 void *d_workspace, size_t workspace_bytes, void *stream_) {
+    using namespace kk;
+    using namespace kk::dvr;
+    KK_REQUIRE(d_tile_cost && d_tile_order && d_workspace, "null pointer");
+    KK_REQUIRE(tiles > 0 && tiles <= KK_LBVH_MAX_FACES, "tile count out of range");
+    const OrderWs w = order_ws(tiles);
+    if (workspace_bytes < w.total) {
+        set_error("tile order workspace too small: %zu < %zu", workspace_bytes, w.total);
+        return KK_ERR_WORKSPACE;
+    }
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    char *b = static_cast<char *>(d_workspace);
+    uint32_t *keysA = reinterpret_cast<uint32_t *>(b + w.keysA);
+    tile_keys_kernel<<<div_up(tiles, THREADS), THREADS, 0, stream>>>(d_tile_cost, tiles, keysA);
+    KK_LAUNCH_CHECK();
+    // two 8-bit passes over the 16-bit keys leave the sorted tiles in the A arrays, i.e. in d_tile_order
+    return rsort::sort_pairs(keysA, reinterpret_cast<uint32_t *>(b + w.keysB), d_tile_order,
+                             reinterpret_cast<uint32_t *>(b + w.valsB), true, tiles, b + w.sortWs, w.sortWsBytes,
+                             stream, nullptr, 2, false);
+}
+#define KK_DVR_ORDERED(SUFFIX, TYPE)                                                                          \
+    extern "C" int kk_dvr_render_ordered_##SUFFIX(                                                            \
+        const kk_vdb_device_data *h_vdb, const float *d_tf, const kk_dvr_params *h_params,                    \
+        const kk_dvr_frame *h_frame, uint8_t *d_rgba, int width, int height, int y0, int y1,                  \
+        uint32_t *d_tile_cost, const uint32_t *d_tile_order, void *stream) {                                  \
+        return kk::dvr::launch<TYPE>(h_vdb, d_tf, h_params, h_frame, d_rgba, width, height, y0, y1, 0, 1, nullptr, \
+                                     static_cast<hipStream_t>(stream), 0, d_tile_cost, d_tile_order);         \
+    }
+KK_DVR_ORDERED(u8, uint8_t)
+KK_DVR_ORDERED(u16, uint16_t)
+#undef KK_DVR_ORDERED
 
 extern "C" int kk_dvr_render_u8(const kk_vdb_device_data *h_vdb, const float *d_tf,
                                 const kk_dvr_params *h_params, const kk_dvr_frame *h_frame,

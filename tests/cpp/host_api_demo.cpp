@@ -151,6 +151,16 @@ int main(int argc, char **argv) {
         dfb2.ReadBack(img);
         save(out + "/dvr_rgba_own_stream.u8", img);
     }
+    { // and with the tiles started in the order of the frame before: the second such frame is ordered
+        caster.SetAdaptiveTileOrder(true);
+        HIP::FrameBuffer dfb3(dsz);
+        caster.RenderDepthBoxVDB<uint8_t>(dfb3, dsz);
+        caster.RenderDepthBoxVDB<uint8_t>(dfb3, dsz);
+        kk_stream_synchronize(nullptr);
+        dfb3.ReadBack(img);
+        save(out + "/dvr_rgba_adaptive_order.u8", img);
+        caster.SetAdaptiveTileOrder(false);
+    }
     // the several-GPU calls with a one-rank communicator: both structures broadcast (each a single
     // allocation), the frame rendered as compact stripes, gathered and put back in image order
     {

@@ -87,6 +87,7 @@ def test_cpp_host_classes_match_checker(oracle, veach, tmp_path):
                                 dc.rotation(), DW, DH)
     dgot = np.fromfile(outd / "dvr_rgba.u8", np.uint8).reshape(DH, DW, 4)
     assert np.fromfile(outd / "dvr_rgba_own_stream.u8", np.uint8).tobytes() == dgot.tobytes()
+    assert np.fromfile(outd / "dvr_rgba_adaptive_order.u8", np.uint8).tobytes() == dgot.tobytes()
     np.testing.assert_array_equal(dgot[..., 3], want[..., 3])
     assert np.abs(dgot[..., :3].astype(int) - want[..., :3].astype(int)).max() <= 1
     # the one-rank communicator round trip: the gathered frame is the frame; the tracer still works on

@@ -202,6 +202,63 @@ def test_frames_in_flight_on_two_streams_equal_serial_frames(oracle):
         assert fbs[i].ReadBack().tobytes() == serial[i].tobytes(), f"frame {i}"
 
 
+def test_adaptive_tile_order_gives_the_same_frames(oracle):
+    """The order in which a frame's tiles are started comes from the tile times of the frame before; the
+    frames themselves are those of the plain launch order, for whole frames and for a range of rows
+    whose height is no multiple of the tile, and the order the library makes is the sort of the times."""
+    from raytracer_amd import _lib
+    dim = (64, 128, 128)
+    vol = syn.head_volume(dim)
+    vdb, ref = _build_both(oracle, vol, (4, 3, 3), HEAD_TF.empty_scalar_ranges)
+    W, H = 330, 250
+    _, _, _, _, caster, fb = _render_both(oracle, vdb, ref, HEAD_TF, dim, (2, 1, 1), W, H)
+    poses = []
+    for orbit in (0, 3, 6, 90, 93, 200):
+        _, c, _ = dvr_setup(dim, (2, 1, 1), W, H, 1.0, orbit)
+        poses.append((c.pos, c.rotation()))
+    for rows in (None, (37, 190)):
+        caster.SetAdaptiveTileOrder(False)
+        plain = []
+        for pose in poses:
+            caster.SetCameraToWorld(*pose)
+            fb.rgba.zero_()
+            caster.RenderDepthBoxVDB(fb, rows=rows)
+            torch.cuda.synchronize()
+            plain.append(fb.ReadBack().copy())
+        caster.SetAdaptiveTileOrder(True)
+        for i, pose in enumerate(poses):
+            caster.SetCameraToWorld(*pose)
+            fb.rgba.zero_()
+            caster.RenderDepthBoxVDB(fb, rows=rows)
+            torch.cuda.synchronize()
+            assert fb.ReadBack().tobytes() == plain[i].tobytes(), f"rows {rows} frame {i}"
+            st = caster._tile_state
+            n_rows = H if rows is None else rows[1] - rows[0]
+            assert st["n"] == -(-W // 16) * -(-n_rows // 16) == _lib.lib().kk_dvr_tile_count(W, n_rows)
+            cost = st["cost"].cpu().numpy().astype(np.int64)
+            order = st["order"].cpu().numpy().astype(np.int64)
+            assert cost.min() >= 1 and cost.max() <= 65535
+            # costly tiles first, ties by tile number: a stable sort by descending cost
+            assert np.array_equal(order, np.argsort(-cost, kind="stable"))
+    caster.SetAdaptiveTileOrder(False)
+
+
+def test_tile_order_rejections():
+    from raytracer_amd import _lib
+    l = _lib.lib()
+    assert l.kk_dvr_tile_count(0, 16) == 0 and l.kk_dvr_tile_count(17, 1) == 2
+    n = 100
+    cost = torch.zeros(n, dtype=torch.int32, device=DEV)
+    order = torch.zeros(n, dtype=torch.int32, device=DEV)
+    ws = torch.zeros(int(l.kk_dvr_tile_order_workspace_bytes(n)), dtype=torch.uint8, device=DEV)
+    assert l.kk_dvr_tile_order(cost.data_ptr(), n, order.data_ptr(), ws.data_ptr(), ws.numel() - 1, None) != 0
+    assert l.kk_dvr_tile_order(None, n, order.data_ptr(), ws.data_ptr(), ws.numel(), None) != 0
+    assert l.kk_dvr_tile_order(cost.data_ptr(), 0, order.data_ptr(), ws.data_ptr(), ws.numel(), None) != 0
+    assert l.kk_dvr_tile_order(cost.data_ptr(), n, order.data_ptr(), ws.data_ptr(), ws.numel(), None) == 0
+    torch.cuda.synchronize()
+    assert order.cpu().tolist() == list(range(n))  # equal costs: the tiles' own order
+
+
 def test_render_without_vdb_reports_and_returns(capsys):
     RayCaster(DEV).RenderDepthBoxVDB(FrameBuffer(8, 8, DEV))
     assert "vdb or tfTex are not set" in capsys.readouterr().err
