@@ -66,12 +66,18 @@ def run(dev: str, world: int, rank: int, dist=None, frames: int = 720, warmup: i
         bcast_ms = (time.perf_counter() - t0) * 1e3
 
     scales = cam.volume_scales((2, 1, 1) if head else (1, 1, 1), dim)
-    caster = RayCaster(dev)
-    caster.SetWorldToScene(cam.world_to_scene(scales))
-    caster.SetDepthBoxVDB(vdb)
-    caster.SetTransferFunctionTexture(TransferFunctionTable(tf.dat, dev))
     proj = cam.perspective_fov(cam.radians(90.0), W, H, 1.0, 3.0)
-    caster.SetProjection(proj)
+    tf_table = TransferFunctionTable(tf.dat, dev)
+
+    def make_caster():
+        rc = RayCaster(dev)
+        rc.SetWorldToScene(cam.world_to_scene(scales))
+        rc.SetDepthBoxVDB(vdb)
+        rc.SetTransferFunctionTexture(tf_table)
+        rc.SetProjection(proj)
+        return rc
+
+    caster = make_caster()
     c = cam.FPSCamera((0, 0, float(max(scales))), (0, 0, 0))
     # the orbit's camera poses, computed once (host work of the reference's frame loop)
     poses = []
@@ -181,22 +187,29 @@ def run(dev: str, world: int, rank: int, dist=None, frames: int = 720, warmup: i
         streams = two_streams(dev)
         fbs = [FrameBuffer(W, H, dev), FrameBuffer(W, H, dev)]
 
-        def frame2(i):
-            caster.SetCameraToWorld(*poses[i])
-            with torch.cuda.stream(streams[i & 1]):
-                caster.RenderDepthBoxVDB(fbs[i & 1])
+        # a caster per stream: the tile order belongs to one stream's sequence of frames
+        casters = [make_caster(), make_caster()]
 
-        for i in range(warmup):
-            frame2(i)
-        torch.cuda.synchronize()
-        t2 = time.perf_counter()
-        for i in range(warmup, warmup + frames):
-            frame2(i)
-        torch.cuda.synchronize()
-        wall2 = time.perf_counter() - t2
-        out["fps_two_frames_in_flight"] = round(frames / wall2, 2)
+        def frame2(i):
+            casters[i & 1].SetCameraToWorld(*poses[i])
+            with torch.cuda.stream(streams[i & 1]):
+                casters[i & 1].RenderDepthBoxVDB(fbs[i & 1])
+
         last = warmup + frames - 1
-        out["two_in_flight_last_frame_equals_serial"] = bool(torch.equal(fbs[last & 1].rgba, fb.rgba))
+        for key, adaptive in (("fps_two_frames_in_flight_launch_order", False), ("fps_two_frames_in_flight", True)):
+            for rc in casters:
+                rc.SetAdaptiveTileOrder(adaptive)
+            for i in range(warmup):
+                frame2(i)
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            for i in range(warmup, warmup + frames):
+                frame2(i)
+            torch.cuda.synchronize()
+            out[key] = round(frames / (time.perf_counter() - t2), 2)
+            out["two_in_flight_last_frame_equals_serial"] = bool(
+                out.get("two_in_flight_last_frame_equals_serial", True) and
+                torch.equal(fbs[last & 1].rgba, fb.rgba))
         # work counters of one frame: samples taken and bricks entered
         counters = torch.zeros(2, dtype=torch.int64, device=dev)
         caster.SetCameraToWorld(*poses[warmup])
