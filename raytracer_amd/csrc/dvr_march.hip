@@ -1057,12 +1057,20 @@ int launch(const kk_vdb_device_data *h_vdb, const float *d_tf, const kk_dvr_para
     return KK_OK;
 }
 
-// keys for the sort that puts the costly tiles first: the cost, complemented
+// Keys for the sort that puts the costly tiles first (the cost, complemented), and the counts of their two
+// digits for the sort's passes (radix_hist.h): a few workgroups, each over a share of the tiles.
+constexpr uint32_t TILE_KEY_GROUPS = 16;
 __global__ __launch_bounds__(THREADS) void tile_keys_kernel(const uint32_t *__restrict__ cost, uint32_t n,
-                                                            uint32_t *__restrict__ keys) {
-    const uint32_t i = blockIdx.x * THREADS + threadIdx.x;
-    if (i < n)
-        keys[i] = 65535u - (cost[i] > 65535u ? 65535u : cost[i]);
+                                                            uint32_t *__restrict__ keys,
+                                                            uint32_t *__restrict__ ghist) {
+    __shared__ uint32_t s_hist[2 * rsort::HIST_RADIX];
+    rsort::hist_clear<2>(s_hist, threadIdx.x, THREADS);
+    for (uint32_t i = blockIdx.x * THREADS + threadIdx.x; i < n; i += gridDim.x * THREADS) {
+        const uint32_t key = 65535u - (cost[i] > 65535u ? 65535u : cost[i]);
+        keys[i] = key;
+        rsort::hist_add<2>(s_hist, key);
+    }
+    rsort::hist_flush<2>(s_hist, ghist, threadIdx.x, THREADS);
 }
 
 struct OrderWs {
@@ -1101,12 +1109,17 @@ extern "C" int kk_dvr_tile_order(const uint32_t *d_tile_cost, uint32_t tiles, ui
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     char *b = static_cast<char *>(d_workspace);
     uint32_t *keysA = reinterpret_cast<uint32_t *>(b + w.keysA);
-    tile_keys_kernel<<<div_up(tiles, THREADS), THREADS, 0, stream>>>(d_tile_cost, tiles, keysA);
+    uint32_t *ghist = nullptr;
+    const int rc = rsort::sort_prepare(b + w.sortWs, w.sortWsBytes, tiles, stream, &ghist);
+    if (rc != KK_OK)
+        return rc;
+    const uint32_t grid = div_up(tiles, THREADS) < TILE_KEY_GROUPS ? div_up(tiles, THREADS) : TILE_KEY_GROUPS;
+    tile_keys_kernel<<<grid, THREADS, 0, stream>>>(d_tile_cost, tiles, keysA, ghist);
     KK_LAUNCH_CHECK();
     // two 8-bit passes over the 16-bit keys leave the sorted tiles in the A arrays, i.e. in d_tile_order
     return rsort::sort_pairs(keysA, reinterpret_cast<uint32_t *>(b + w.keysB), d_tile_order,
                              reinterpret_cast<uint32_t *>(b + w.valsB), true, tiles, b + w.sortWs, w.sortWsBytes,
-                             stream, nullptr, 2, false);
+                             stream, nullptr, 2, true);
 }
 #define KK_DVR_ORDERED(SUFFIX, TYPE)                                                                          \
     extern "C" int kk_dvr_render_ordered_##SUFFIX(                                                            \

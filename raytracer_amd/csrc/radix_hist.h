@@ -17,7 +17,9 @@ constexpr int HIST_RADIX = 256;
 constexpr int HIST_COPIES = 8;
 constexpr int HIST_COPY_STRIDE = 4 * HIST_RADIX; // four digit rows per copy
 
-int sort_prepare(void *ws, size_t wsBytes, uint32_t n, hipStream_t stream, uint32_t **ghistOut);
+// (alsoClearBefore: bytes of the caller's own, directly before ws, to be cleared by the same memset)
+int sort_prepare(void *ws, size_t wsBytes, uint32_t n, hipStream_t stream, uint32_t **ghistOut,
+                 size_t alsoClearBefore = 0);
 int sort_pairs(uint32_t *keysA, uint32_t *keysB, uint32_t *valsA, uint32_t *valsB, bool iota, uint32_t n,
                void *ws, size_t wsBytes, hipStream_t stream, uint32_t **errorFlagOut, int passes,
                bool prepared = false);

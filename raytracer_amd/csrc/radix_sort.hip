@@ -287,13 +287,14 @@ inline SortWs sort_ws(uint32_t n) {
 // is in the B arrays.
 // Clears the sort's workspace and names its histogram rows (row p = digit p, 256 words each), for a
 // caller whose own kernel counts the digits (radix_hist.h).
-int sort_prepare(void *ws, size_t wsBytes, uint32_t n, hipStream_t stream, uint32_t **ghistOut) {
+int sort_prepare(void *ws, size_t wsBytes, uint32_t n, hipStream_t stream, uint32_t **ghistOut,
+                 size_t alsoClearBefore) {
     SortWs w = sort_ws(n);
     if (wsBytes < w.total) {
         set_error("sort workspace too small: %zu < %zu", wsBytes, w.total);
         return KK_ERR_WORKSPACE;
     }
-    KK_HIP_TRY(hipMemsetAsync(ws, 0, w.total, stream));
+    KK_HIP_TRY(hipMemsetAsync(static_cast<char *>(ws) - alsoClearBefore, 0, w.total + alsoClearBefore, stream));
     *ghistOut = reinterpret_cast<uint32_t *>(static_cast<char *>(ws) + w.ghist);
     return KK_OK;
 }

@@ -984,12 +984,13 @@ inline TraceWs trace_ws(uint32_t rayNum) {
     TraceWs w;
     Carver c;
     const size_t n = rayNum ? rayNum : 1;
-    w.counter = c.take(4 * QUEUES * QUEUE_STRIDE); // ray queue heads
     w.spill = c.take(sizeof(uint2) * MAX_GRID * THREADS * (STACK_DEPTH - LDS_DEPTH));
     w.keysA = c.take(4 * n);
     w.keysB = c.take(4 * n);
     w.valsA = c.take(4 * n);
     w.valsB = c.take(4 * n);
+    // the ray queue heads sit right before the sort's workspace: one clear covers both
+    w.counter = c.take(4 * QUEUES * QUEUE_STRIDE);
     w.sortWsBytes = kk_sort_workspace_bytes(static_cast<uint32_t>(n));
     w.sortWs = c.take(w.sortWsBytes);
     w.total = c.off;
@@ -1149,7 +1150,9 @@ extern "C" int kk_closest_hit_accel(const void *d_accel, uint32_t face_num,
     const auto *recs = reinterpret_cast<const TriRec *>(ab + l.tris);
     char *b = static_cast<char *>(d_workspace);
     uint32_t *rayCounter = reinterpret_cast<uint32_t *>(b + w.counter);
-    KK_HIP_TRY(hipMemsetAsync(rayCounter, 0, 4 * QUEUES * QUEUE_STRIDE, stream));
+    const bool sorts = !(flags & (KK_TRACE_REUSE_ORDER | KK_TRACE_UNSORTED));
+    if (!sorts)
+        KK_HIP_TRY(hipMemsetAsync(rayCounter, 0, 4 * QUEUES * QUEUE_STRIDE, stream));
 
     const uint32_t *order = nullptr;
     if (flags & KK_TRACE_REUSE_ORDER) {
@@ -1159,7 +1162,8 @@ extern "C" int kk_closest_hit_accel(const void *d_accel, uint32_t face_num,
         auto *valsA = reinterpret_cast<uint32_t *>(b + w.valsA);
         auto *valsB = reinterpret_cast<uint32_t *>(b + w.valsB);
         uint32_t *ghist = nullptr;
-        int rc = rsort::sort_prepare(b + w.sortWs, w.sortWsBytes, ray_num, stream, &ghist);
+        int rc = rsort::sort_prepare(b + w.sortWs, w.sortWsBytes, ray_num, stream, &ghist,
+                                     w.sortWs - w.counter); // ... and the queue heads before it
         if (rc != KK_OK)
             return rc;
         uint32_t kgrid = div_up(ray_num, THREADS);
