@@ -85,10 +85,10 @@ def run(dev: str, world: int, rank: int, dist=None, frames: int = 720, warmup: i
         c.Revolve(cam._c("sqrtf", cam._dot(c.pos, c.pos)), 0.5, 0.0)
         poses.append((c.pos.copy(), c.rotation().copy()))
     fb = FrameBuffer(W, H, dev)
-    # One GPU renders whole frames and starts each frame's tiles in the order of what they took in the
-    # frame before (the sort of the tile times is inside the timed loop); the same loop in plain launch
-    # order is timed beside it. Several GPUs render interleaved stripes, which are launched as they are.
-    caster.SetAdaptiveTileOrder(world == 1)
+    # Each frame's tiles (of the whole frame, or of this rank's stripes) are started in the order of what
+    # they took in the frame before; the sort of the tile times is inside the timed loop. With one GPU
+    # the same loop in plain launch order is timed beside it.
+    caster.SetAdaptiveTileOrder(True)
     gatherer = None
     if world > 1:
         from raytracer_amd.multi_gpu import StripeGatherer

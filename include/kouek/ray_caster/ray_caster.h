@@ -102,20 +102,14 @@ class RayCaster : Noncopyable {
         void *s = stream ? stream->Get() : nullptr;
         if (adaptiveTileOrder && rndrTarget == DPBXVDBRenderTarget::Scene && rndrSz.x > 0 && rndrSz.y > 0) {
             const uint32_t tiles = kk_dvr_tile_count(rndrSz.x, rndrSz.y);
-            if (tiles != tileCost.size()) {
-                haveTileOrder = false;
-                if (!tileCost.resize(tiles) || !tileOrder.resize(tiles) ||
-                    !tileOrderWs.resize(kk_dvr_tile_order_workspace_bytes(tiles)))
-                    return;
-            }
+            if (!prepareTileOrder({rndrSz.x, rndrSz.y, 0, 0}, tiles))
+                return;
             auto ordered = sizeof(T) == 1 ? kk_dvr_render_ordered_u8 : kk_dvr_render_ordered_u16;
             if (KOUEK_HIP_CHECK(ErrTag.data(),
                                 ordered(&vdb->GetDeviceData(), tfTex->Get(), &rndrParam, &rndrParamPerFrame,
                                         rndrTo.Get(), rndrSz.x, rndrSz.y, 0, rndrSz.y, tileCost.data(),
                                         haveTileOrder ? tileOrder.data() : nullptr, s)))
-                haveTileOrder = KOUEK_HIP_CHECK(ErrTag.data(),
-                                                kk_dvr_tile_order(tileCost.data(), tiles, tileOrder.data(),
-                                                                  tileOrderWs.data(), tileOrderWs.size(), s));
+                sortTileOrder(tiles, s);
             return;
         }
         auto fn = sizeof(T) == 1 ? kk_dvr_render_target_u8 : kk_dvr_render_target_u16;
@@ -151,10 +145,26 @@ class RayCaster : Noncopyable {
             return;
         if (r == root && stripeBlocks.size() != blockBytes * n && !stripeBlocks.resize(blockBytes * n))
             return;
-        auto fn = sizeof(T) == 1 ? kk_dvr_render_stripes_compact_u8 : kk_dvr_render_stripes_compact_u16;
-        if (!KOUEK_HIP_CHECK(ErrTag.data(), fn(&vdb->GetDeviceData(), tfTex->Get(), &rndrParam, &rndrParamPerFrame,
-                                               stripeSend.data(), rndrSz.x, rndrSz.y, r, n, nullptr, nullptr)) ||
-            !KOUEK_HIP_CHECK(ErrTag.data(), kk_gather_stripes(comm.Get(), stripeSend.data(), stripeBlocks.data(),
+        const uint32_t tiles = adaptiveTileOrder ? kk_dvr_stripe_tile_count(rndrSz.x, rndrSz.y, r, n) : 0u;
+        if (tiles > 0) { // this rank's tiles in the order of what they took in its frame before
+            if (!prepareTileOrder({rndrSz.x, rndrSz.y, r + 1, n}, tiles))
+                return;
+            auto ordered = sizeof(T) == 1 ? kk_dvr_render_stripes_compact_ordered_u8
+                                          : kk_dvr_render_stripes_compact_ordered_u16;
+            if (!KOUEK_HIP_CHECK(ErrTag.data(),
+                                 ordered(&vdb->GetDeviceData(), tfTex->Get(), &rndrParam, &rndrParamPerFrame,
+                                         stripeSend.data(), rndrSz.x, rndrSz.y, r, n, tileCost.data(),
+                                         haveTileOrder ? tileOrder.data() : nullptr, nullptr)))
+                return;
+            sortTileOrder(tiles, nullptr);
+        } else {
+            auto fn = sizeof(T) == 1 ? kk_dvr_render_stripes_compact_u8 : kk_dvr_render_stripes_compact_u16;
+            if (!KOUEK_HIP_CHECK(ErrTag.data(),
+                                 fn(&vdb->GetDeviceData(), tfTex->Get(), &rndrParam, &rndrParamPerFrame,
+                                    stripeSend.data(), rndrSz.x, rndrSz.y, r, n, nullptr, nullptr)))
+                return;
+        }
+        if (!KOUEK_HIP_CHECK(ErrTag.data(), kk_gather_stripes(comm.Get(), stripeSend.data(), stripeBlocks.data(),
                                                               rndrSz.x, rndrSz.y, root, nullptr)))
             return;
         if (r == root)
@@ -167,6 +177,25 @@ class RayCaster : Noncopyable {
     HIP::DeviceBuffer<uint8_t> stripeSend, stripeBlocks, tileOrderWs;
     HIP::DeviceBuffer<uint32_t> tileCost, tileOrder;
     bool adaptiveTileOrder = false, haveTileOrder = false;
+    struct TileLaunch { // which launch the tile times belong to: image size and the stripes rendered
+        int w = 0, h = 0, first = 0, stride = 0;
+        bool operator==(const TileLaunch &o) const {
+            return w == o.w && h == o.h && first == o.first && stride == o.stride;
+        }
+    } tileLaunch;
+    // buffers for `tiles` tiles of launch `now`; a launch other than the last one starts in launch order
+    bool prepareTileOrder(const TileLaunch &now, uint32_t tiles) {
+        if (now == tileLaunch && tiles == tileCost.size())
+            return true;
+        haveTileOrder = false;
+        tileLaunch = now;
+        return tileCost.resize(tiles) && tileOrder.resize(tiles) &&
+               tileOrderWs.resize(kk_dvr_tile_order_workspace_bytes(tiles));
+    }
+    void sortTileOrder(uint32_t tiles, void *s) {
+        haveTileOrder = KOUEK_HIP_CHECK(ErrTag.data(), kk_dvr_tile_order(tileCost.data(), tiles, tileOrder.data(),
+                                                                         tileOrderWs.data(), tileOrderWs.size(), s));
+    }
 };
 
 } // namespace RayCaster

@@ -487,6 +487,19 @@ int kk_dvr_render_ordered_u16(const kk_vdb_device_data *h_vdb, const float *d_tf
                               const kk_dvr_params *h_params, const kk_dvr_frame *h_frame, uint8_t *d_rgba,
                               int width, int height, int y0, int y1, uint32_t *d_tile_cost,
                               const uint32_t *d_tile_order, void *stream);
+/* The same for the compact stripes of one GPU (kk_dvr_render_stripes_compact_* below): the tiles are those
+ * of this GPU's stripes, row by row, kk_dvr_stripe_tile_count of them. */
+uint32_t kk_dvr_stripe_tile_count(int width, int height, int stripe_first, int stripe_stride);
+int kk_dvr_render_stripes_compact_ordered_u8(const kk_vdb_device_data *h_vdb, const float *d_tf,
+                                             const kk_dvr_params *h_params, const kk_dvr_frame *h_frame,
+                                             uint8_t *d_stripes, int width, int height, int stripe_first,
+                                             int stripe_stride, uint32_t *d_tile_cost,
+                                             const uint32_t *d_tile_order, void *stream);
+int kk_dvr_render_stripes_compact_ordered_u16(const kk_vdb_device_data *h_vdb, const float *d_tf,
+                                              const kk_dvr_params *h_params, const kk_dvr_frame *h_frame,
+                                              uint8_t *d_stripes, int width, int height, int stripe_first,
+                                              int stripe_stride, uint32_t *d_tile_cost,
+                                              const uint32_t *d_tile_order, void *stream);
 size_t kk_dvr_tile_order_workspace_bytes(uint32_t tiles);
 int kk_dvr_tile_order(const uint32_t *d_tile_cost, uint32_t tiles, uint32_t *d_tile_order, void *d_workspace,
                       size_t workspace_bytes, void *stream);

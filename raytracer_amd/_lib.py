@@ -129,6 +129,10 @@ def _declare(l):
     for sfx in ("u8", "u16"):
         getattr(l, f"kk_dvr_render_stripes_compact_{sfx}").argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]
         getattr(l, f"kk_dvr_render_ordered_{sfx}").argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp]
+        getattr(l, f"kk_dvr_render_stripes_compact_ordered_{sfx}").argtypes = [
+            vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp]
+    l.kk_dvr_stripe_tile_count.restype = u32
+    l.kk_dvr_stripe_tile_count.argtypes = [i32, i32, i32, i32]
     l.kk_dvr_tile_count.restype = u32
     l.kk_dvr_tile_count.argtypes = [i32, i32]
     l.kk_dvr_tile_order_workspace_bytes.restype = sz

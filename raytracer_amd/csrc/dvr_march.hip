@@ -1183,6 +1183,25 @@ extern "C" int kk_dvr_render_stripes_compact_u16(const kk_vdb_device_data *h_vdb
                                      stripe_first, stripe_stride, d_counters,
                                      static_cast<hipStream_t>(stream), 1);
 }
+// the compact stripes of one GPU with the tile order and tile times of kk_dvr_render_ordered_*
+extern "C" uint32_t kk_dvr_stripe_tile_count(int width, int height, int stripe_first, int stripe_stride) {
+    if (width <= 0 || height <= 0 || stripe_first < 0 || stripe_stride < 1)
+        return 0u;
+    const int stripes = static_cast<int>(kk::div_up(height, 16));
+    return stripe_first >= stripes ? 0u : kk::div_up(width, 16) * kk::div_up(stripes - stripe_first, stripe_stride);
+}
+#define KK_DVR_STRIPES_ORDERED(SUFFIX, TYPE)                                                                  \
+    extern "C" int kk_dvr_render_stripes_compact_ordered_##SUFFIX(                                            \
+        const kk_vdb_device_data *h_vdb, const float *d_tf, const kk_dvr_params *h_params,                    \
+        const kk_dvr_frame *h_frame, uint8_t *d_stripes, int width, int height, int stripe_first,             \
+        int stripe_stride, uint32_t *d_tile_cost, const uint32_t *d_tile_order, void *stream) {               \
+        return kk::dvr::launch<TYPE>(h_vdb, d_tf, h_params, h_frame, d_stripes, width, height, 0, height,     \
+                                     stripe_first, stripe_stride, nullptr, static_cast<hipStream_t>(stream),  \
+                                     1, d_tile_cost, d_tile_order);                                           \
+    }
+KK_DVR_STRIPES_ORDERED(u8, uint8_t)
+KK_DVR_STRIPES_ORDERED(u16, uint16_t)
+#undef KK_DVR_STRIPES_ORDERED
 extern "C" int kk_raw_render_u8(const uint8_t *d_volume, uint32_t dx, uint32_t dy, uint32_t dz,
                                 const float *d_tf, const kk_dvr_params *h_params,
                                 const kk_dvr_frame *h_frame, int target, uint8_t *d_rgba, int width,

@@ -40,26 +40,38 @@ class RayCaster:
         self._tile_state = None
 
     def SetAdaptiveTileOrder(self, on: bool = True):
-        """Start each Scene frame's 16 x 16 tiles in the order of what they took in the frame before,
-        the costly ones first. The image is the same; the frame is shorter because the longest rays no
+        """Start each Scene frame's 16 x 16 tiles (whole frames, row ranges, and one GPU's compact
+        stripes) in the order of what they took in the frame before, the costly ones first. The image is the same; the frame is shorter because the longest rays no
         longer start last. The state belongs to this object's sequence of frames on one stream: frames
         in flight on several streams take a RayCaster each. No counterpart in the reference, whose
         launch order is the tiles' own (src/ray_caster/ray_caster_dpbx_vdb.cu:1027-1034)."""
         self._adaptive = bool(on)
         self._tile_state = None
 
-    def _tiles(self, width, rows):
-        """Cost, order and sort workspace of the adaptive tile order for a width x rows render."""
+    def _tiles(self, key, n):
+        """Cost, order and sort workspace of the adaptive tile order for a launch of n tiles; `key` names
+        the launch (size, rows or stripes), a different one starts over in launch order."""
         st = self._tile_state
-        if st is None or st["key"] != (width, rows):
-            n = int(_lib.lib().kk_dvr_tile_count(width, rows))
+        if st is None or st["key"] != key:
             ws = int(_lib.lib().kk_dvr_tile_order_workspace_bytes(n))
-            st = {"key": (width, rows), "n": n, "have": False,
+            st = {"key": key, "n": n, "have": False,
                   "cost": torch.zeros(n, dtype=torch.int32, device=self.device),
                   "order": torch.zeros(n, dtype=torch.int32, device=self.device),
                   "ws": torch.zeros(ws, dtype=torch.uint8, device=self.device)}
             self._tile_state = st
         return st
+
+    def _render_ordered(self, fn, st, *args):
+        """One ordered launch (fn's arguments up to the tile arrays in args) and the sort of its tile times
+        for the next one, on the current stream."""
+        with torch.cuda.device(self.device):
+            stream = _lib.current_stream_ptr()
+            _lib.check(fn(*args, st["cost"].data_ptr(), st["order"].data_ptr() if st["have"] else None, stream),
+                       "kk_dvr_render_ordered")
+            _lib.check(_lib.lib().kk_dvr_tile_order(
+                st["cost"].data_ptr(), st["n"], st["order"].data_ptr(), st["ws"].data_ptr(),
+                st["ws"].numel(), stream), "kk_dvr_tile_order")
+        st["have"] = True
 
     @staticmethod
     def _fill(arr, value):
@@ -162,18 +174,21 @@ class RayCaster:
             fn = getattr(_lib.lib(), f"kk_dvr_render_{sfx}")
             a, b = rows if rows is not None else (0, fb.height)
             if self._adaptive and counters is None and b > a:
-                st = self._tiles(fb.width, int(b) - int(a))
-                with torch.cuda.device(self.device):
-                    stream = _lib.current_stream_ptr()
-                    _lib.check(getattr(_lib.lib(), f"kk_dvr_render_ordered_{sfx}")(
-                        C.byref(self.vdb.GetDeviceData()), self.tf.tensor.data_ptr(), C.byref(self._params),
-                        C.byref(self._frame), out_ptr, fb.width, fb.height, int(a), int(b),
-                        st["cost"].data_ptr(), st["order"].data_ptr() if st["have"] else None, stream),
-                        "kk_dvr_render_ordered")
-                    _lib.check(_lib.lib().kk_dvr_tile_order(
-                        st["cost"].data_ptr(), st["n"], st["order"].data_ptr(), st["ws"].data_ptr(),
-                        st["ws"].numel(), stream), "kk_dvr_tile_order")
-                st["have"] = True
+                n = int(_lib.lib().kk_dvr_tile_count(fb.width, int(b) - int(a)))
+                self._render_ordered(
+                    getattr(_lib.lib(), f"kk_dvr_render_ordered_{sfx}"),
+                    self._tiles(("rows", fb.width, fb.height, int(a), int(b)), n),
+                    C.byref(self.vdb.GetDeviceData()), self.tf.tensor.data_ptr(), C.byref(self._params),
+                    C.byref(self._frame), out_ptr, fb.width, fb.height, int(a), int(b))
+                return
+        if self._adaptive and counters is None and stripes is not None and compact_out is not None:
+            n = int(_lib.lib().kk_dvr_stripe_tile_count(fb.width, fb.height, int(a), int(b)))
+            if n > 0:
+                self._render_ordered(
+                    getattr(_lib.lib(), f"kk_dvr_render_stripes_compact_ordered_{sfx}"),
+                    self._tiles(("stripes", fb.width, fb.height, int(a), int(b)), n),
+                    C.byref(self.vdb.GetDeviceData()), self.tf.tensor.data_ptr(), C.byref(self._params),
+                    C.byref(self._frame), out_ptr, fb.width, fb.height, int(a), int(b))
                 return
         with torch.cuda.device(self.device):
             _lib.check(fn(C.byref(self.vdb.GetDeviceData()), self.tf.tensor.data_ptr(),

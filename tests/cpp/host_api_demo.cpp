@@ -177,6 +177,12 @@ int main(int argc, char **argv) {
             caster.RenderDepthBoxVDBGathered<uint8_t>(gfb, dsz, comm, 0);
             gfb.ReadBack(img);
             save(out + "/dvr_gathered_rgba.u8", img);
+            caster.SetAdaptiveTileOrder(true); // twice: the second frame's tiles start in the first's order
+            caster.RenderDepthBoxVDBGathered<uint8_t>(gfb, dsz, comm, 0);
+            caster.RenderDepthBoxVDBGathered<uint8_t>(gfb, dsz, comm, 0);
+            caster.SetAdaptiveTileOrder(false);
+            gfb.ReadBack(img);
+            save(out + "/dvr_gathered_adaptive_rgba.u8", img);
             // the tree is still the tree after its broadcast: one more sample on top
             tracer.Render(fb, sz);
             save(out + "/pt_accum_after_broadcast.f32", tracer.ReadAccumulation());

@@ -95,6 +95,7 @@ def test_cpp_host_classes_match_checker(oracle, veach, tmp_path):
     if os.path.exists(outd / "dvr_gathered_rgba.u8"):
         ggot = np.fromfile(outd / "dvr_gathered_rgba.u8", np.uint8)
         assert ggot.tobytes() == dgot.tobytes()
+        assert np.fromfile(outd / "dvr_gathered_adaptive_rgba.u8", np.uint8).tobytes() == dgot.tobytes()
         oracle.pt_render_sample(ref, arr, np.eye(4, dtype=np.float32), cam.inverse_projective(proj),
                                 c.pos, c.rotation(), acc, img, float(spp + 1))
         got3 = np.fromfile(outd / "pt_accum_after_broadcast.f32", np.float32).reshape(H, W, 3)

@@ -243,6 +243,35 @@ def test_adaptive_tile_order_gives_the_same_frames(oracle):
     caster.SetAdaptiveTileOrder(False)
 
 
+def test_adaptive_tile_order_of_compact_stripes(oracle):
+    """One GPU's compact stripes (stripes 1, 4, 7, ... of the frame) with the tile order on are the
+    stripes rendered in launch order, frame after frame."""
+    from raytracer_amd import _lib
+    dim = (64, 128, 128)
+    vol = syn.head_volume(dim)
+    vdb, ref = _build_both(oracle, vol, (4, 3, 3), HEAD_TF.empty_scalar_ranges)
+    W, H = 330, 250
+    _, _, _, _, caster, fb = _render_both(oracle, vdb, ref, HEAD_TF, dim, (2, 1, 1), W, H)
+    first, stride = 1, 3
+    per = int(_lib.lib().kk_stripes_per_rank(H, stride))
+    plain = torch.zeros(per, 16, W, 4, dtype=torch.uint8, device=DEV)
+    ordered = torch.zeros_like(plain)
+    caster.SetAdaptiveTileOrder(True)
+    for orbit in (0, 4, 8, 120):
+        _, c, _ = dvr_setup(dim, (2, 1, 1), W, H, 1.0, orbit)
+        caster.SetCameraToWorld(c.pos, c.rotation())
+        caster._adaptive = False  # (the setter would drop the tile times of the frame before)
+        caster.RenderDepthBoxVDB(fb, stripes=(first, stride), compact_out=plain)
+        caster._adaptive = True
+        caster.RenderDepthBoxVDB(fb, stripes=(first, stride), compact_out=ordered)
+        torch.cuda.synchronize()
+        assert torch.equal(plain, ordered), f"orbit {orbit}"
+        st = caster._tile_state
+        assert st["n"] == _lib.lib().kk_dvr_stripe_tile_count(W, H, first, stride) == -(-W // 16) * 5
+    assert caster._tile_state["have"] and int(plain.max()) > 0
+    caster.SetAdaptiveTileOrder(False)
+
+
 def test_tile_order_rejections():
     from raytracer_amd import _lib
     l = _lib.lib()
