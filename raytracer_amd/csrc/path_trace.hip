@@ -437,7 +437,6 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(WAVES, 
     __shared__ uint32_t s_rec[THREADS];           // ... and the record of an owner's winning triangle
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const unsigned long long lanesBelow = (1ull << lane) - 1ull;
     const LaneStack st{s_stack + tid, s_bits + tid, THREADS};
     uint2 deep[LANE_DEPTH - LANE_LDS_DEPTH];
 
@@ -765,7 +764,8 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(WAVES, 
                     poolEmpty = ++queuesTried == NQ; // wave-uniform
                 }
                 if (stage == ST_IDLE) {
-                    const uint32_t q = base + __popcll(idleMask & lanesBelow);
+                    // idle lanes below this one (mbcnt: no lane mask kept in registers)
+                    const uint32_t q = base + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(idleMask >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(idleMask), 0u));
                     if (q < qLen && q >= base) {
                         const uint32_t tile = (q >> 6) * NQ + firstTile, in = q & 63u;
                         const uint32_t tx = tile % tilesX, ty = tile / tilesX;

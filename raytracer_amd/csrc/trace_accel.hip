@@ -733,7 +733,6 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(5, 5)))
     const int lane = tid & 63;
     uint32_t *stBase = s_base + tid;
     unsigned short *stBits = s_bits + tid;
-    const unsigned long long lanesBelow = (1ull << lane) - 1ull;
     const size_t spillStride = static_cast<size_t>(gridDim.x) * THREADS;
     uint2 *mySpill = spill + static_cast<size_t>(blockIdx.x) * THREADS + tid;
     const kk_lbvh_node *nodes = hdr->nodes;
@@ -818,7 +817,8 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(5, 5)))
                 poolEmpty = ++queuesTried == QUEUES;
             }
             if (!active) {
-                const uint32_t rel = base + __popcll(idleMask & lanesBelow);
+                // idle lanes below this one (mbcnt: no lane mask kept in registers)
+                const uint32_t rel = base + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(idleMask >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(idleMask), 0u));
                 if (rel < qLen && rel >= base) {
                     const uint32_t r = qBegin + rel;
                     rayIdx = order ? order[r] : r;
