@@ -475,8 +475,9 @@ int kk_dvr_render_u16(const kk_vdb_device_data *h_vdb, const float *d_tf,
  * renderer knows that from the frame before. Tiles are numbered row by row over the rendered rows
  * (kk_dvr_tile_count(width, y1 - y0) of them). d_tile_order (optional): a permutation of the tile numbers,
  * workgroup n renders tile d_tile_order[n]. d_tile_cost (optional): uint32 per tile, the time the tile's
- * workgroup took, in units of 64 clock cycles, capped at 65535. kk_dvr_tile_order sorts the tiles by cost,
- * the costly ones first (ties by tile number), into d_tile_order. The image does not depend on the order.
+ * workgroup took, in units of 64 clock cycles, capped at 65535. kk_dvr_tile_order sorts the tiles by cost
+ * class (256 classes, sixteen to a doubling of the cost), the costly ones first, ties by tile number, into
+ * d_tile_order. The image does not depend on the order.
  * No counterpart in the reference, whose launch order is the tiles' own. The buffers belong to one
  * sequence of frames: frames in flight on different streams need a set each. */
 uint32_t kk_dvr_tile_count(int width, int rows);

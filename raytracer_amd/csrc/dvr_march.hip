@@ -1057,31 +1057,39 @@ int launch(const kk_vdb_device_data *h_vdb, const float *d_tf, const kk_dvr_para
     return KK_OK;
 }
 
-// Keys for the sort that puts the costly tiles first (the cost, complemented), and the counts of their two
-// digits for the sort's passes (radix_hist.h): a few workgroups, each over a share of the tiles.
+// The cost of a tile in 256 classes, sixteen to a doubling: the place of its leading one and the four bits
+// below it. A list schedule needs no finer order, and eight bits sort in one pass.
+__host__ __device__ __forceinline__ uint32_t tile_cost_class(uint32_t cost) {
+    const uint32_t c = cost > 65535u ? 65535u : cost;
+    uint32_t e = 0;
+    while ((c >> (e + 1u)) != 0u)
+        ++e;
+    return (e << 4) | ((e >= 4u ? c >> (e - 4u) : c << (4u - e)) & 15u);
+}
+// Keys for the sort that puts the costly tiles first (the cost class, complemented), and the counts of
+// their digit for the sort's pass (radix_hist.h): a few workgroups, each over a share of the tiles.
 constexpr uint32_t TILE_KEY_GROUPS = 16;
 __global__ __launch_bounds__(THREADS) void tile_keys_kernel(const uint32_t *__restrict__ cost, uint32_t n,
                                                             uint32_t *__restrict__ keys,
                                                             uint32_t *__restrict__ ghist) {
-    __shared__ uint32_t s_hist[2 * rsort::HIST_RADIX];
-    rsort::hist_clear<2>(s_hist, threadIdx.x, THREADS);
+    __shared__ uint32_t s_hist[rsort::HIST_RADIX];
+    rsort::hist_clear<1>(s_hist, threadIdx.x, THREADS);
     for (uint32_t i = blockIdx.x * THREADS + threadIdx.x; i < n; i += gridDim.x * THREADS) {
-        const uint32_t key = 65535u - (cost[i] > 65535u ? 65535u : cost[i]);
+        const uint32_t key = 255u - tile_cost_class(cost[i]);
         keys[i] = key;
-        rsort::hist_add<2>(s_hist, key);
+        rsort::hist_add<1>(s_hist, key);
     }
-    rsort::hist_flush<2>(s_hist, ghist, threadIdx.x, THREADS);
+    rsort::hist_flush<1>(s_hist, ghist, threadIdx.x, THREADS);
 }
 
 struct OrderWs {
-    size_t keysA, keysB, valsB, sortWs, sortWsBytes, total;
+    size_t keysA, keysB, sortWs, sortWsBytes, total;
 };
 inline OrderWs order_ws(uint32_t tiles) {
     OrderWs w;
     Carver c;
     w.keysA = c.take(4 * static_cast<size_t>(tiles));
     w.keysB = c.take(4 * static_cast<size_t>(tiles));
-    w.valsB = c.take(4 * static_cast<size_t>(tiles));
     w.sortWsBytes = kk_sort_workspace_bytes(tiles);
     w.sortWs = c.take(w.sortWsBytes);
     w.total = c.off;
@@ -1116,10 +1124,9 @@ extern "C" int kk_dvr_tile_order(const uint32_t *d_tile_cost, uint32_t tiles, ui
     const uint32_t grid = div_up(tiles, THREADS) < TILE_KEY_GROUPS ? div_up(tiles, THREADS) : TILE_KEY_GROUPS;
     tile_keys_kernel<<<grid, THREADS, 0, stream>>>(d_tile_cost, tiles, keysA, ghist);
     KK_LAUNCH_CHECK();
-    // two 8-bit passes over the 16-bit keys leave the sorted tiles in the A arrays, i.e. in d_tile_order
-    return rsort::sort_pairs(keysA, reinterpret_cast<uint32_t *>(b + w.keysB), d_tile_order,
-                             reinterpret_cast<uint32_t *>(b + w.valsB), true, tiles, b + w.sortWs, w.sortWsBytes,
-                             stream, nullptr, 2, true);
+    // one 8-bit pass from the A arrays (whose values are the tile numbers themselves) into the B arrays
+    return rsort::sort_pairs(keysA, reinterpret_cast<uint32_t *>(b + w.keysB), nullptr, d_tile_order, true, tiles,
+                             b + w.sortWs, w.sortWsBytes, stream, nullptr, 1, true);
 }
 #define KK_DVR_ORDERED(SUFFIX, TYPE)                                                                          \
     extern "C" int kk_dvr_render_ordered_##SUFFIX(                                                            \

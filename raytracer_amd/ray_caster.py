@@ -37,28 +37,33 @@ class RayCaster:
         self._display_lev = 0
         self._display_leaf_layer = 0
         self._adaptive = False
+        self._tile_states = {}
         self._tile_state = None
 
     def SetAdaptiveTileOrder(self, on: bool = True):
         """Start each Scene frame's 16 x 16 tiles (whole frames, row ranges, and one GPU's compact
-        stripes) in the order of what they took in the frame before, the costly ones first. The image is the same; the frame is shorter because the longest rays no
-        longer start last. The state belongs to this object's sequence of frames on one stream: frames
+        stripes) in the order of what they took in the frame before, the costly ones first. The image
+        is the same; the frame is shorter because the longest rays no longer start last. The state belongs to this object's sequence of frames on one stream: frames
         in flight on several streams take a RayCaster each. No counterpart in the reference, whose
         launch order is the tiles' own (src/ray_caster/ray_caster_dpbx_vdb.cu:1027-1034)."""
         self._adaptive = bool(on)
+        self._tile_states = {}
         self._tile_state = None
 
     def _tiles(self, key, n):
         """Cost, order and sort workspace of the adaptive tile order for a launch of n tiles; `key` names
-        the launch (size, rows or stripes), a different one starts over in launch order."""
-        st = self._tile_state
-        if st is None or st["key"] != key:
+        the launch (size, rows or stripes); every launch keeps its own tile times."""
+        st = self._tile_states.get(key)
+        if st is None:
+            if len(self._tile_states) >= 8:  # an application alternates between a few launches at most
+                self._tile_states.clear()
             ws = int(_lib.lib().kk_dvr_tile_order_workspace_bytes(n))
             st = {"key": key, "n": n, "have": False,
                   "cost": torch.zeros(n, dtype=torch.int32, device=self.device),
                   "order": torch.zeros(n, dtype=torch.int32, device=self.device),
                   "ws": torch.zeros(ws, dtype=torch.uint8, device=self.device)}
-            self._tile_state = st
+            self._tile_states[key] = st
+        self._tile_state = st  # the launch rendered last
         return st
 
     def _render_ordered(self, fn, st, *args):

@@ -202,6 +202,14 @@ def test_frames_in_flight_on_two_streams_equal_serial_frames(oracle):
         assert fbs[i].ReadBack().tobytes() == serial[i].tobytes(), f"frame {i}"
 
 
+def _cost_class(cost):
+    """The place of the leading one and the four bits below it (kk_dvr_tile_order's sort key)."""
+    c = np.minimum(cost, 65535).astype(np.int64)
+    e = np.floor(np.log2(np.maximum(c, 1))).astype(np.int64)
+    m = np.where(e >= 4, c >> np.maximum(e - 4, 0), c << np.maximum(4 - e, 0)) & 15
+    return (e << 4) | m
+
+
 def test_adaptive_tile_order_gives_the_same_frames(oracle):
     """The order in which a frame's tiles are started comes from the tile times of the frame before; the
     frames themselves are those of the plain launch order, for whole frames and for a range of rows
@@ -238,8 +246,8 @@ def test_adaptive_tile_order_gives_the_same_frames(oracle):
             cost = st["cost"].cpu().numpy().astype(np.int64)
             order = st["order"].cpu().numpy().astype(np.int64)
             assert cost.min() >= 1 and cost.max() <= 65535
-            # costly tiles first, ties by tile number: a stable sort by descending cost
-            assert np.array_equal(order, np.argsort(-cost, kind="stable"))
+            # costly tiles first, by cost class (sixteen to a doubling), ties by tile number
+            assert np.array_equal(order, np.argsort(-_cost_class(cost), kind="stable"))
     caster.SetAdaptiveTileOrder(False)
 
 
@@ -286,6 +294,12 @@ def test_tile_order_rejections():
     assert l.kk_dvr_tile_order(cost.data_ptr(), n, order.data_ptr(), ws.data_ptr(), ws.numel(), None) == 0
     torch.cuda.synchronize()
     assert order.cpu().tolist() == list(range(n))  # equal costs: the tiles' own order
+    cost.copy_(torch.tensor([0, 1, 2, 3, 15, 16, 17, 31, 32, 33, 1000, 1023, 1024, 65535, 65536, 2 ** 31 - 1]
+                            + [5] * (n - 16), dtype=torch.int32))
+    assert l.kk_dvr_tile_order(cost.data_ptr(), n, order.data_ptr(), ws.data_ptr(), ws.numel(), None) == 0
+    torch.cuda.synchronize()
+    want = np.argsort(-_cost_class(cost.cpu().numpy().astype(np.int64)), kind="stable")
+    assert order.cpu().tolist() == want.tolist()
 
 
 def test_render_without_vdb_reports_and_returns(capsys):
