@@ -235,9 +235,12 @@ __global__ __launch_bounds__(THREADS) void dvr_kernel(const kk_vdb_device_data v
     const uint32_t tileX = tileId % gridDim.x, tileY = tileId / gridDim.x;
     __shared__ float4 s_tf[TF_LDS];
     __shared__ float s_norm[256];
+    __shared__ uint32_t s_tileTime, s_wavesDone;
     const int tid = threadIdx.x;
     tfStage(s_tf, tf, tid);
     s_norm[tid] = static_cast<float>(tid) / 255.f;
+    if (tid == 0)
+        s_tileTime = s_wavesDone = 0u;
     __syncthreads();
     const Norm<T> norm{s_norm};
 
@@ -586,9 +589,14 @@ __global__ __launch_bounds__(THREADS) void dvr_kernel(const kk_vdb_device_data v
             atomicAdd(&counters[1], nBricks);
         }
     }
-    if (tileCost != nullptr && tid == 0) { // in units of 64 cycles, so that any frame's tiles fit 16 bits
+    // What the tile took = what its slowest wave took, in units of 64 cycles (so that any frame's tiles fit
+    // 16 bits): every wave leaves its time in LDS, and the one that leaves last writes the largest. (No
+    // barrier: a wave that is done frees its registers for the next workgroup.)
+    if (tileCost != nullptr && lane == 0) {
         const long long took = (clock64() - tileStart) >> 6;
-        tileCost[tileId] = took > 65535ll ? 65535u : static_cast<uint32_t>(took);
+        atomicMax(&s_tileTime, took > 65535ll ? 65535u : static_cast<uint32_t>(took));
+        if (atomicAdd(&s_wavesDone, 1u) == THREADS / 64 - 1) // LDS operations of a wave complete in order
+            tileCost[tileId] = atomicMax(&s_tileTime, 0u);
     }
 }
 
