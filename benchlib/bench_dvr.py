@@ -153,6 +153,52 @@ def run(dev: str, world: int, rank: int, dist=None, frames: int = 720, warmup: i
             caster.RenderDepthBoxVDB(fb)
             torch.cuda.synchronize()
             same_frame = bool(torch.equal(got, fb.rgba))
+    fps2 = same_frame2 = None
+    if dist:
+        # Two frames in flight on every rank: a rank's share of a frame is bound by its longest rays (an
+        # eighth of the stripes takes more than half the time of all of them), so the next frame's stripes
+        # are rendered beside it on a second stream, with a caster (and thus a tile order), a frame buffer
+        # and a slot of the gatherer per stream. The gathers stay in frame order on the gatherer's stream.
+        from benchlib import two_streams
+        from raytracer_amd.multi_gpu import StripeGatherer
+        streams = two_streams(dev)
+        casters2 = [make_caster(), make_caster()]
+        for rc in casters2:
+            rc.SetAdaptiveTileOrder(True)
+        fbs2 = [fb, FrameBuffer(W, H, dev)]
+        g2 = StripeGatherer(W, H, world, rank, dev, dst=0, comm=comm)
+
+        def frame2(i):
+            k = i & 1
+            casters2[k].SetCameraToWorld(*poses[i])
+            with torch.cuda.stream(streams[k]):
+                buf = g2.begin(fbs2[k].rgba)
+                casters2[k].RenderDepthBoxVDB(fbs2[k], stripes=(rank, world), compact_out=buf)
+                g2.submit()
+
+        for i in range(warmup & ~1):  # an even count: slot and stream keep their pairing
+            frame2(i)
+        torch.cuda.synchronize()
+        g2.flush(fb.rgba)
+        torch.cuda.synchronize()
+        dist.barrier()
+        t2 = time.perf_counter()
+        first = warmup & ~1
+        for i in range(first, first + frames):
+            frame2(i)
+        torch.cuda.synchronize()
+        g2.flush(fb.rgba)  # the last two frames' assembly on rank 0 is inside the time
+        torch.cuda.synchronize()
+        dist.barrier()
+        tt = torch.tensor([time.perf_counter() - t2], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        fps2 = frames / float(tt.item())
+        if rank == 0:
+            got = fb.rgba.clone()
+            caster.SetCameraToWorld(*poses[first + frames - 1])
+            caster.RenderDepthBoxVDB(fb)
+            torch.cuda.synchronize()
+            same_frame2 = bool(torch.equal(got, fb.rgba))
     if rank != 0:
         return {}
     out = {"workload": f"{'Head' if head else 'Kingsnake'}-shape {dim[0]}x{dim[1]}x{dim[2]} uint8, {W}x{H}, "
@@ -165,6 +211,8 @@ def run(dev: str, world: int, rank: int, dist=None, frames: int = 720, warmup: i
         out["render_only_ms_per_frame"] = round(render_only_ms, 4)
         out["gather_us_per_frame"] = round((wall * 1e3 / frames - render_only_ms) * 1e3, 1)
         out["gathered_frame_equals_single_gpu"] = same_frame
+        out["fps_two_frames_in_flight"] = round(fps2, 2)
+        out["two_in_flight_gathered_frame_equals_single_gpu"] = same_frame2
         out["transport"] = "kk_comm (library RCCL)" if comm is not None else f"torch.distributed/{dist.get_backend()}"
     if world == 1:
         adaptive_last = fb.rgba.clone()

@@ -31,3 +31,7 @@ def test_two_rank_rehearsal():
     assert out["dvr"]["gathered_frame_equals_single_gpu"] is True
     assert out["dvr_head_1080p"]["gathered_frame_equals_single_gpu"] is True
     assert "gather_us_per_frame" in out["dvr"] and out["dvr"]["render_only_ms_per_frame"] > 0
+    # ... and so is the last frame of the loop that keeps two frames in flight on every rank
+    assert out["dvr"]["fps_two_frames_in_flight"] > 0
+    assert out["dvr"]["two_in_flight_gathered_frame_equals_single_gpu"] is True
+    assert out["dvr_head_1080p"]["two_in_flight_gathered_frame_equals_single_gpu"] is True

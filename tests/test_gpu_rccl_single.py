@@ -140,4 +140,48 @@ def test_library_communicator_one_rank():
     for a, b in zip(got, want):
         assert a.tobytes() == b.tobytes()
     assert (want[0][..., 3] > 0).mean() > 0.05
+
+    # the same with two frames in flight: frames alternate over two streams, each with its own caster
+    # (adaptive tile order on), frame buffer and gatherer slot; the gathers keep frame order on the
+    # gatherer's stream
+    streams = [torch.cuda.Stream(DEV), torch.cuda.Stream(DEV)]
+    casters = []
+    for _ in range(2):
+        rc = RayCaster(DEV)
+        rc.SetDepthBoxVDB(vdb)
+        rc.SetTransferFunctionTexture(TransferFunctionTable(HEAD_TF.dat, DEV))
+        rc.SetAdaptiveTileOrder(True)
+        casters.append(rc)
+    fbs = [FrameBuffer(W, H, DEV), FrameBuffer(W, H, DEV)]
+    g2 = multi_gpu.StripeGatherer(W, H, 1, 0, DEV, comm=comm)
+    orbits = (0, 9, 40, 77, 120, 200)
+    want2, got2 = [], {}
+    for orbit in orbits:
+        w2s, c, proj = dvr_setup(dim, (2, 1, 1), W, H, 1.0, orbit)
+        caster.SetWorldToScene(w2s)
+        caster.SetProjection(proj)
+        caster.SetCameraToWorld(c.pos, c.rotation())
+        caster.RenderDepthBoxVDB(whole)
+        torch.cuda.synchronize()
+        want2.append(whole.ReadBack().copy())
+    for i, orbit in enumerate(orbits):
+        k = i & 1
+        w2s, c, proj = dvr_setup(dim, (2, 1, 1), W, H, 1.0, orbit)
+        casters[k].SetWorldToScene(w2s)
+        casters[k].SetProjection(proj)
+        casters[k].SetCameraToWorld(c.pos, c.rotation())
+        with torch.cuda.stream(streams[k]):
+            buf = g2.begin(fbs[k].rgba)  # assembles frame i - 2 into fbs[k] on this stream
+            if i >= 2:
+                streams[k].synchronize()
+                got2[i - 2] = fbs[k].ReadBack().copy()
+            casters[k].RenderDepthBoxVDB(fbs[k], stripes=(0, 1), compact_out=buf)
+            g2.submit()
+    torch.cuda.synchronize()
+    for i in (len(orbits) - 2, len(orbits) - 1):
+        g2._wait(i & 1, fbs[i & 1].rgba)  # frame i went through slot i & 1
+        torch.cuda.synchronize()
+        got2[i] = fbs[i & 1].ReadBack().copy()
+    for i in range(len(orbits)):
+        assert got2[i].tobytes() == want2[i].tobytes(), f"frame {i}"
     comm.close()
