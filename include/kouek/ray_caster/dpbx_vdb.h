@@ -81,20 +81,26 @@ class DepthBoxVDB : Noncopyable {
         if (kk_vdb_plan_build(dim[0], dim[1], dim[2], cfg.log2Dims.data(), cfg.apronWid, cfg.useDepthBox,
                               valid.data(), &plan) != KK_OK)
             return fail();
-        std::vector<Node> nodes(plan.node_num);
-        std::vector<RelativeIndexTy> children(plan.child_num), amap(plan.atlas_map_num);
-        if (kk_vdb_wire(&plan, valid.data(), nodes.data(), children.data(), amap.data()) != KK_OK)
-            return fail();
         this->plan = plan;
         voxelBytes = sizeof(T);
         if (!allocBlob())
             return fail();
+        // the atlas is filled from leaf positions made on the GPU (kk_vdb_leaf_nodes) while the host wires
+        // the pools; these go over afterwards
+        HIP::DeviceBuffer<Node> d_leafNodes(plan.leaf_num);
+        if (kk_vdb_leaf_nodes(d_valid.data(), &plan, reinterpret_cast<kk_vdb_node *>(d_leafNodes.data()), nullptr) !=
+                KK_OK ||
+            Fn<T>::fill(cfg.volTex.Get(), dim[0], dim[1], dim[2], &plan,
+                        reinterpret_cast<const kk_vdb_node *>(d_leafNodes.data()), rngs.data(), nRng,
+                        static_cast<T *>(deviceDat.atlas), nullptr) != KK_OK)
+            return fail();
+        std::vector<Node> nodes(plan.node_num);
+        std::vector<RelativeIndexTy> children(plan.child_num), amap(plan.atlas_map_num);
+        if (kk_vdb_wire(&plan, valid.data(), nodes.data(), children.data(), amap.data()) != KK_OK)
+            return fail();
         if (kk_memcpy_h2d(deviceDat.node_pools, nodes.data(), sizeof(Node) * nodes.size(), nullptr) != KK_OK ||
             kk_memcpy_h2d(deviceDat.child_pools, children.data(), 4 * children.size(), nullptr) != KK_OK ||
             kk_memcpy_h2d(deviceDat.atlas_brick_to_node_indices, amap.data(), 4 * amap.size(), nullptr) != KK_OK)
-            return fail();
-        if (Fn<T>::fill(cfg.volTex.Get(), dim[0], dim[1], dim[2], &plan, deviceDat.node_pools, rngs.data(), nRng,
-                        static_cast<T *>(deviceDat.atlas), nullptr) != KK_OK)
             return fail();
         kk_stream_synchronize(nullptr);
         std::cout << "Build VDB with\n\tNode pools of size " << plan.node_num << "x" << sizeof(Node)

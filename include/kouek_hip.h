@@ -418,6 +418,13 @@ int kk_vdb_classify_u16(const uint16_t *d_volume, uint32_t dx, uint32_t dy, uint
 int kk_vdb_plan_build(uint32_t dx, uint32_t dy, uint32_t dz, const uint8_t log2_dims[3],
                       uint8_t apron_wid, int use_depth_box, const uint32_t *h_leaf_valid,
                       kk_vdb_plan *out);
+/* Optional, between steps 2 and 4 (device): the leaf nodes' `pos` fields made on the GPU from the same
+ * validity flags (leaf k = the k-th valid brick in the pools' (x, y, z) order), into an array of
+ * plan->leaf_num nodes of the caller's. kk_vdb_fill_atlas_* reads nothing else of the nodes it is given,
+ * so with this array in place of d_node_pools the atlas can be filled while the host still runs step 3.
+ * No counterpart in the reference, which wires on the host first (dpbx_vdb.cu:173-330). */
+int kk_vdb_leaf_nodes(const uint32_t *d_leaf_valid, const kk_vdb_plan *plan, kk_vdb_node *d_leaf_nodes,
+                      void *stream);
 /* Step 3 (host only): fills node pools (sorted by level, then x, y, z; root last), dense child pools
  * (index (z << 2L) | (y << L) | x, undefined = 0xFFFFFFFF) and the atlas map (dpbx_vdb.cu:57-115,
  * 404-445, 524-571) into caller-allocated host arrays of the planned sizes. */

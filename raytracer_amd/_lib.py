@@ -156,6 +156,7 @@ def _declare(l):
     l.kk_unstripe_rgba.argtypes = [vp, i32, i32, i32, vp, vp]
     l.kk_vdb_plan_build.argtypes = [u32, u32, u32, vp, C.c_uint8, i32, vp, vp]
     l.kk_vdb_wire.argtypes = [vp, vp, vp, vp, vp]
+    l.kk_vdb_leaf_nodes.argtypes = [vp, vp, vp, vp]
     for name in ("kk_malloc", "kk_free", "kk_memcpy_h2d", "kk_memcpy_d2h", "kk_memset",
                  "kk_stream_synchronize", "kk_set_device"):
         getattr(l, name).restype = i32

@@ -370,6 +370,48 @@ int classify(const T *d_volume, uint32_t dx, uint32_t dy, uint32_t dz, uint32_t 
     return KK_OK;
 }
 
+// The leaf nodes' positions made on the GPU from the validity flags, so that the atlas can be filled while
+// the host still wires the pools: leaf k is the k-th valid brick in (x, y, z) order, x slowest (the order
+// of the pools, dpbx_vdb.cu:40-51). One workgroup: every thread counts the valid bricks of its share of
+// that order, a scan over the threads gives its first k, a second walk writes the positions. The other
+// fields of the nodes are left alone (the atlas fill reads `pos` only).
+constexpr int LEAF_NODES_THREADS = 1024;
+__global__ __launch_bounds__(LEAF_NODES_THREADS) void leaf_nodes_kernel(const uint32_t *__restrict__ leafValid,
+                                                                      uint32_t lx, uint32_t ly, uint32_t lz,
+                                                                      uint32_t B, uint32_t leafNum,
+                                                                      kk_vdb_node *__restrict__ nodes) {
+    __shared__ uint32_t s_count[LEAF_NODES_THREADS];
+    const uint32_t total = lx * ly * lz, tid = threadIdx.x;
+    const uint32_t per = (total + LEAF_NODES_THREADS - 1) / LEAF_NODES_THREADS;
+    const uint32_t first = tid * per, last = first + per < total ? first + per : total;
+    // position n of the (x, y, z) order: x = n / (ly lz), y = (n / lz) % ly, z = n % lz
+    auto flagAt = [&](uint32_t n) {
+        const uint32_t x = n / (ly * lz), y = (n / lz) % ly, z = n % lz;
+        return leafValid[(static_cast<size_t>(z) * ly + y) * lx + x] != 0u;
+    };
+    uint32_t mine = 0;
+    for (uint32_t n = first; n < last; ++n)
+        mine += flagAt(n) ? 1u : 0u;
+    s_count[tid] = mine;
+    __syncthreads();
+    for (uint32_t o = 1; o < LEAF_NODES_THREADS; o <<= 1) { // inclusive scan over the threads
+        const uint32_t add = tid >= o ? s_count[tid - o] : 0u;
+        __syncthreads();
+        s_count[tid] += add;
+        __syncthreads();
+    }
+    uint32_t k = s_count[tid] - mine;
+    for (uint32_t n = first; n < last; ++n)
+        if (flagAt(n)) {
+            if (k < leafNum) { // (more valid bricks than the plan counted: flags changed; the host checks)
+                nodes[k].pos[0] = static_cast<int32_t>(n / (ly * lz) * B);
+                nodes[k].pos[1] = static_cast<int32_t>((n / lz) % ly * B);
+                nodes[k].pos[2] = static_cast<int32_t>(n % lz * B);
+            }
+            ++k;
+        }
+}
+
 template <typename T>
 int fillAtlas(const T *d_volume, uint32_t dx, uint32_t dy, uint32_t dz, const kk_vdb_plan *plan,
               const kk_vdb_node *d_node_pools, const T *h_rngs, uint32_t n, T *d_atlas, void *stream) {
@@ -421,13 +463,13 @@ struct Coord {
 static void levelCoords(const kk_vdb_plan &plan, const uint32_t *leafValid,
                         std::vector<Coord> levels[KK_VDB_MAX_LEVEL_NUM]) {
     const uint32_t lx = plan.leaf_slots[0], ly = plan.leaf_slots[1], lz = plan.leaf_slots[2];
-    for (uint32_t z = 0; z < lz; ++z)
+    // x outermost: the leaves come out in (x, y, z) order, the order of the pools, without a sort
+    for (uint32_t x = 0; x < lx; ++x)
         for (uint32_t y = 0; y < ly; ++y)
-            for (uint32_t x = 0; x < lx; ++x)
+            for (uint32_t z = 0; z < lz; ++z)
                 if (leafValid[(static_cast<size_t>(z) * ly + y) * lx + x])
                     levels[0].push_back({static_cast<int32_t>(x), static_cast<int32_t>(y),
                                          static_cast<int32_t>(z)});
-    std::sort(levels[0].begin(), levels[0].end());
     for (int lev = 1; lev <= plan.param.root_lev; ++lev) {
         const int32_t d = plan.param.dims[lev];
         for (const Coord &c : levels[lev - 1])
@@ -526,6 +568,20 @@ extern "C" int kk_vdb_plan_build(uint32_t dx, uint32_t dy, uint32_t dz, const ui
     out->child_num = children;
     const uint64_t A = p.vox_per_atlas_brick;
     out->atlas_voxels = A * A * A * out->leaf_num;
+    return KK_OK;
+}
+
+extern "C" int kk_vdb_leaf_nodes(const uint32_t *d_leaf_valid, const kk_vdb_plan *plan, kk_vdb_node *d_leaf_nodes,
+                                 void *stream) {
+    using namespace kk;
+    KK_REQUIRE(d_leaf_valid && plan && d_leaf_nodes, "null pointer");
+    KK_REQUIRE(plan->leaf_num > 0, "no leaves");
+    const uint64_t total = static_cast<uint64_t>(plan->leaf_slots[0]) * plan->leaf_slots[1] * plan->leaf_slots[2];
+    KK_REQUIRE(total > 0 && total < (1ull << 31), "brick count out of range");
+    vdb::leaf_nodes_kernel<<<1, vdb::LEAF_NODES_THREADS, 0, static_cast<hipStream_t>(stream)>>>(
+        d_leaf_valid, plan->leaf_slots[0], plan->leaf_slots[1], plan->leaf_slots[2],
+        static_cast<uint32_t>(plan->param.dims[0]), plan->leaf_num, d_leaf_nodes);
+    KK_LAUNCH_CHECK();
     return KK_OK;
 }
 

@@ -124,27 +124,34 @@ class DepthBoxVDB:
                                            h_valid.ctypes.data_as(C.c_void_p), C.byref(plan)),
                        "kk_vdb_plan_build")
             tw.append(time.perf_counter())
-            nodes = np.zeros(int(plan.node_num), NODE_DTYPE)
-            children = np.zeros(int(plan.child_num), np.uint32)
-            amap = np.zeros(int(plan.atlas_map_num), np.uint32)
+            # The atlas fill starts at once, with the leaves' positions made on the GPU from the flags
+            # (kk_vdb_leaf_nodes), and runs while the host wires the pools. The three small arrays are
+            # wired where they lie in the blob (they come before the atlas), so one copy carries them over.
+            self.alloc_blob(plan, vol.itemsize)
+            lay = self.blob_layout
+            leaf_nodes = torch.empty(int(plan.leaf_num) * 32, dtype=torch.uint8, device=dev)
+            _lib.check(l.kk_vdb_leaf_nodes(d_valid.data_ptr(), C.byref(plan), leaf_nodes.data_ptr(), stream),
+                       "kk_vdb_leaf_nodes")
+            ev[2].record()
+            _lib.check(getattr(l, f"kk_vdb_fill_atlas_{sfx}")(
+                vol.tensor.data_ptr(), vol.dx, vol.dy, vol.dz, C.byref(plan), leaf_nodes.data_ptr(),
+                rng_p, rng.shape[0], self.d_atlas.data_ptr(), stream), "kk_vdb_fill_atlas")
+            ev[3].record()
+            tw.append(time.perf_counter())
+            head = np.zeros(int(lay.atlas), np.uint8)
+            nodes = head[int(lay.node_pools):int(lay.node_pools) + int(plan.node_num) * 32].view(NODE_DTYPE)
+            children = head[int(lay.child_pools):int(lay.child_pools) + int(plan.child_num) * 4].view(np.uint32)
+            amap = head[int(lay.atlas_map):int(lay.atlas_map) + int(plan.atlas_map_num) * 4].view(np.uint32)
             _lib.check(l.kk_vdb_wire(C.byref(plan), h_valid.ctypes.data_as(C.c_void_p),
                                      nodes.ctypes.data_as(C.c_void_p), children.ctypes.data_as(C.c_void_p),
                                      amap.ctypes.data_as(C.c_void_p)), "kk_vdb_wire")
             tw.append(time.perf_counter())
-            self.alloc_blob(plan, vol.itemsize)
-            self.d_node_pools.copy_(torch.from_numpy(nodes.view(np.uint8)))
-            self.d_child_pools.copy_(torch.from_numpy(children.view(np.int32)))
-            self.d_atlas_brick_to_node.copy_(torch.from_numpy(amap.view(np.int32)))
-            tw.append(time.perf_counter())
-            ev[2].record()
-            _lib.check(getattr(l, f"kk_vdb_fill_atlas_{sfx}")(
-                vol.tensor.data_ptr(), vol.dx, vol.dy, vol.dz, C.byref(plan), self.d_node_pools.data_ptr(),
-                rng_p, rng.shape[0], self.d_atlas.data_ptr(), stream), "kk_vdb_fill_atlas")
-            ev[3].record()
+            self.d_blob[:int(lay.atlas)].copy_(torch.from_numpy(head))
             torch.cuda.synchronize(dev)
         tw.append(time.perf_counter())
         self.timings = {"classify_ms": ev[0].elapsed_time(ev[1]), "fill_atlas_ms": ev[2].elapsed_time(ev[3])}
-        for k, name in enumerate(("classify_and_readback", "plan", "wire", "upload_alloc", "fill_and_sync")):
+        for k, name in enumerate(("classify_and_readback", "plan", "alloc_and_launch_fill", "wire",
+                                  "upload_and_sync")):
             self.timings["host_" + name + "_ms"] = (tw[k + 1] - tw[k]) * 1e3
         self.host_nodes, self.host_children, self.host_atlas_map = nodes, children, amap
 
