@@ -40,6 +40,19 @@ class Volume:
         return np.uint8 if self.itemsize == 1 else np.uint16
 
 
+_PINNED = {}
+
+
+def _pinned(name: str, nbytes: int) -> "torch.Tensor":
+    """A page-locked host buffer of at least nbytes, kept per purpose and device and grown when needed
+    (builds on one device are taken to follow one another, as the class is used)."""
+    t = _PINNED.get(name)
+    if t is None or t.numel() < nbytes:
+        t = torch.empty(max(nbytes, 1), dtype=torch.uint8, pin_memory=True)
+        _PINNED[name] = t
+    return t[:nbytes]
+
+
 class DepthBoxVDB:
     MaxLevelNum = 3
     MaxLog2Dim = 10
@@ -117,7 +130,12 @@ class DepthBoxVDB:
                 vol.tensor.data_ptr(), vol.dx, vol.dy, vol.dz, int(log2_dims[0]), rng_p, rng.shape[0],
                 d_valid.data_ptr(), stream), "kk_vdb_classify")
             ev[1].record()
-            h_valid = d_valid.cpu().numpy().view(np.uint32)
+            # read back through page-locked memory kept from build to build (a pageable copy of these
+            # 100 KB costs twice the time)
+            pinned = _pinned(f"valid@{dev}", n_slots * 4)
+            pinned.copy_(d_valid.view(torch.uint8), non_blocking=True)
+            torch.cuda.current_stream(dev).synchronize()
+            h_valid = pinned.numpy().view(np.uint32)
             tw.append(time.perf_counter())
             plan = _lib.VdbPlan()
             _lib.check(l.kk_vdb_plan_build(vol.dx, vol.dy, vol.dz, l2, int(apron_wid), int(use_depth_box),
@@ -138,7 +156,9 @@ class DepthBoxVDB:
                 rng_p, rng.shape[0], self.d_atlas.data_ptr(), stream), "kk_vdb_fill_atlas")
             ev[3].record()
             tw.append(time.perf_counter())
-            head = np.zeros(int(lay.atlas), np.uint8)
+            head_t = _pinned(f"head@{dev}", int(lay.atlas))
+            head = head_t.numpy()
+            head[:] = 0
             nodes = head[int(lay.node_pools):int(lay.node_pools) + int(plan.node_num) * 32].view(NODE_DTYPE)
             children = head[int(lay.child_pools):int(lay.child_pools) + int(plan.child_num) * 4].view(np.uint32)
             amap = head[int(lay.atlas_map):int(lay.atlas_map) + int(plan.atlas_map_num) * 4].view(np.uint32)
@@ -146,8 +166,11 @@ class DepthBoxVDB:
                                      nodes.ctypes.data_as(C.c_void_p), children.ctypes.data_as(C.c_void_p),
                                      amap.ctypes.data_as(C.c_void_p)), "kk_vdb_wire")
             tw.append(time.perf_counter())
-            self.d_blob[:int(lay.atlas)].copy_(torch.from_numpy(head))
+            self.d_blob[:int(lay.atlas)].copy_(head_t, non_blocking=True)
             torch.cuda.synchronize(dev)
+        # (the host arrays kept below must not alias the page-locked buffers of the next build)
+        nodes, children, amap = nodes.copy(), children.copy(), amap.copy()
+        h_valid = None
         tw.append(time.perf_counter())
         self.timings = {"classify_ms": ev[0].elapsed_time(ev[1]), "fill_atlas_ms": ev[2].elapsed_time(ev[3])}
         for k, name in enumerate(("classify_and_readback", "plan", "alloc_and_launch_fill", "wire",
