@@ -212,23 +212,34 @@ __global__ __launch_bounds__(FILL_THREADS) void fill_atlas_lds_kernel(const T *_
     }
     // row r of direction d: bit i = voxel i along d is not empty. Rows are indexed [outer][inner]:
     // along x (outer z, inner y), along y (outer z, inner x), along z (outer y, inner x).
-    for (int r = tid; r < 3 * A2; r += FILL_THREADS) {
-        const int d = r / A2, outer = (r % A2) / A, inner = r % A;
-        int base, step;
-        if (d == 0) {
-            base = outer * A2 + inner * A;
-            step = 1;
-        } else if (d == 1) {
-            base = outer * A2 + inner;
-            step = A;
-        } else {
-            base = outer * A + inner;
-            step = A2;
-        }
+    // Every voxel is tested once, by the thread that owns its x row (z, y) and keeps that row's mask in a
+    // register. Its bit also belongs to one y row and one z row: the z row (y, x) gets it by an LDS
+    // atomic (the lanes of a wave hold different y, so different words), the y row (z, x) from the
+    // wave's ballot - the lanes that share a z are consecutive y, so their ballot bits, shifted, are a
+    // piece of that row, written by the first of them.
+    for (int i = tid; i < 2 * A2; i += FILL_THREADS)
+        s_mask[A2 + i] = 0ull;
+    __syncthreads();
+    const int lane = tid & 63;
+    for (int r0 = 0; r0 < A2; r0 += FILL_THREADS) { // (whole waves: the ballot needs every lane)
+        const int r = r0 + tid;
+        const bool on = r < A2;
+        const int az = on ? r / A : 0, ay = on ? r % A : 0;
+        const bool leads = on && (ay == 0 || lane == 0); // first lane of the run of lanes with this z
+        const int runLen = (A - ay) < (64 - lane) ? (A - ay) : (64 - lane);
+        const unsigned long long runBits = runLen >= 64 ? ~0ull : ((1ull << runLen) - 1ull);
         unsigned long long m = 0;
-        for (int i = 0; i < A; ++i)
-            m |= static_cast<unsigned long long>(rangeHits(s_vox[base + i * step], rngs) == 0) << i;
-        s_mask[r] = m;
+        for (int ax = 0; ax < A; ++ax) {
+            const bool bit = on && rangeHits(s_vox[r * A + ax], rngs) == 0;
+            m |= static_cast<unsigned long long>(bit) << ax;
+            if (bit)
+                atomicOr(&s_mask[2 * A2 + ay * A + ax], 1ull << az);
+            const unsigned long long seg = (__ballot(bit) >> lane) & runBits;
+            if (leads && seg != 0ull)
+                atomicOr(&s_mask[A2 + az * A + ax], seg << ay);
+        }
+        if (on)
+            s_mask[r] = m;
     }
     __syncthreads();
     const unsigned long long field = (1ull << (B - 1)) - 1ull; // the B - 1 positions a march can stop at
