@@ -387,40 +387,70 @@ int classify(const T *d_volume, uint32_t dx, uint32_t dy, uint32_t dz, uint32_t 
 // that order, a scan over the threads gives its first k, a second walk writes the positions. The other
 // fields of the nodes are left alone (the atlas fill reads `pos` only).
 constexpr int LEAF_NODES_THREADS = 1024;
+constexpr uint32_t LEAF_NODES_STAGED = 48 * 1024;
 __global__ __launch_bounds__(LEAF_NODES_THREADS) void leaf_nodes_kernel(const uint32_t *__restrict__ leafValid,
                                                                       uint32_t lx, uint32_t ly, uint32_t lz,
                                                                       uint32_t B, uint32_t leafNum,
                                                                       kk_vdb_node *__restrict__ nodes) {
-    __shared__ uint32_t s_count[LEAF_NODES_THREADS];
+    __shared__ uint32_t s_count[LEAF_NODES_THREADS / 64];
+    __shared__ uint8_t s_flag[LEAF_NODES_STAGED]; // the flags in memory order, when they fit
     const uint32_t total = lx * ly * lz, tid = threadIdx.x;
     const uint32_t per = (total + LEAF_NODES_THREADS - 1) / LEAF_NODES_THREADS;
     const uint32_t first = tid * per, last = first + per < total ? first + per : total;
-    // position n of the (x, y, z) order: x = n / (ly lz), y = (n / lz) % ly, z = n % lz
-    auto flagAt = [&](uint32_t n) {
-        const uint32_t x = n / (ly * lz), y = (n / lz) % ly, z = n % lz;
-        return leafValid[(static_cast<size_t>(z) * ly + y) * lx + x] != 0u;
-    };
-    uint32_t mine = 0;
-    for (uint32_t n = first; n < last; ++n)
-        mine += flagAt(n) ? 1u : 0u;
-    s_count[tid] = mine;
-    __syncthreads();
-    for (uint32_t o = 1; o < LEAF_NODES_THREADS; o <<= 1) { // inclusive scan over the threads
-        const uint32_t add = tid >= o ? s_count[tid - o] : 0u;
-        __syncthreads();
-        s_count[tid] += add;
+    const bool staged = total <= LEAF_NODES_STAGED; // read once, coalesced; the ordered walks then read LDS
+    if (staged) {
+        for (uint32_t i = tid; i < total; i += LEAF_NODES_THREADS)
+            s_flag[i] = leafValid[i] != 0u ? 1 : 0;
         __syncthreads();
     }
-    uint32_t k = s_count[tid] - mine;
-    for (uint32_t n = first; n < last; ++n)
-        if (flagAt(n)) {
-            if (k < leafNum) { // (more valid bricks than the plan counted: flags changed; the host checks)
-                nodes[k].pos[0] = static_cast<int32_t>(n / (ly * lz) * B);
-                nodes[k].pos[1] = static_cast<int32_t>((n / lz) % ly * B);
-                nodes[k].pos[2] = static_cast<int32_t>(n % lz * B);
+    // position n of the (x, y, z) order: x = n / (ly lz), y = (n / lz) % ly, z = n % lz; a walk keeps the
+    // three coordinates and steps them (z fastest) instead of dividing at every position
+    auto flagAt = [&](uint32_t x, uint32_t y, uint32_t z) {
+        const size_t at = (static_cast<size_t>(z) * ly + y) * lx + x;
+        return staged ? s_flag[at] != 0 : leafValid[at] != 0u;
+    };
+    auto step = [&](uint32_t &x, uint32_t &y, uint32_t &z) {
+        if (++z == lz) {
+            z = 0;
+            if (++y == ly) {
+                y = 0;
+                ++x;
             }
-            ++k;
         }
+    };
+    const uint32_t x0 = first / (ly * lz), y0 = (first / lz) % ly, z0 = first % lz;
+    uint32_t mine = 0;
+    {
+        uint32_t x = x0, y = y0, z = z0;
+        for (uint32_t n = first; n < last; ++n, step(x, y, z))
+            mine += flagAt(x, y, z) ? 1u : 0u;
+    }
+    // exclusive scan of the threads' counts: inside the waves by shuffles, over the waves through LDS
+    const uint32_t lane = tid & 63u, wave = tid >> 6;
+    uint32_t incl = mine;
+    for (uint32_t o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(incl, o, 64);
+        if (lane >= o)
+            incl += t;
+    }
+    if (lane == 63)
+        s_count[wave] = incl;
+    __syncthreads();
+    uint32_t k = incl - mine;
+    for (uint32_t w = 0; w < wave; ++w)
+        k += s_count[w];
+    {
+        uint32_t x = x0, y = y0, z = z0;
+        for (uint32_t n = first; n < last; ++n, step(x, y, z))
+            if (flagAt(x, y, z)) {
+                if (k < leafNum) { // (more valid bricks than the plan counted: flags changed; the host checks)
+                    nodes[k].pos[0] = static_cast<int32_t>(x * B);
+                    nodes[k].pos[1] = static_cast<int32_t>(y * B);
+                    nodes[k].pos[2] = static_cast<int32_t>(z * B);
+                }
+                ++k;
+            }
+    }
 }
 
 template <typename T>
