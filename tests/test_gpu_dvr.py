@@ -54,6 +54,32 @@ def test_build_matches_checker(oracle, shape, l2, dtype, depth):
     _compare_build(vdb, ref)
 
 
+def test_leaf_positions_made_on_the_gpu_are_the_wired_ones(oracle):
+    """kk_vdb_leaf_nodes numbers the valid bricks in the pools' order on the GPU: its positions are those
+    of the host-wired leaf nodes, for a brick grid with unequal edges and for one that is larger than a
+    workgroup's share per thread would make trivial."""
+    import ctypes as C
+    from raytracer_amd import _lib
+    from raytracer_amd.dpbx_vdb import NODE_DTYPE
+    for shape, l2 in (((72, 80, 96), (4, 2, 2)), ((40, 200, 312), (3, 3, 3))):
+        vol = blob_volume(shape, dtype=np.uint8)
+        vdb, ref = _build_both(oracle, vol, l2, SNAKE_TF.empty_scalar_ranges)
+        B = 1 << l2[0]
+        dz, dy, dx = shape
+        lx, ly, lz = -(-dx // B), -(-dy // B), -(-dz // B)
+        valid = np.zeros((lz, ly, lx), np.int32)
+        pos = ref.nodes["pos"][:ref.leaf_num]
+        valid[pos[:, 2] // B, pos[:, 1] // B, pos[:, 0] // B] = 1
+        d_valid = torch.from_numpy(valid.reshape(-1)).to(DEV)
+        out = torch.zeros(ref.leaf_num * 32, dtype=torch.uint8, device=DEV)
+        _lib.check(_lib.lib().kk_vdb_leaf_nodes(d_valid.data_ptr(), C.byref(vdb.plan), out.data_ptr(), None),
+                   "kk_vdb_leaf_nodes")
+        torch.cuda.synchronize()
+        got = out.cpu().numpy().view(NODE_DTYPE)["pos"]
+        np.testing.assert_array_equal(got, pos)
+        assert _lib.lib().kk_vdb_leaf_nodes(None, C.byref(vdb.plan), out.data_ptr(), None) != 0
+
+
 def test_build_head_shape(oracle):
     vol = syn.head_volume()
     vdb, ref = _build_both(oracle, vol, (5, 4, 3), HEAD_TF.empty_scalar_ranges)
