@@ -209,6 +209,11 @@ def main():
         dvr_head = bench_dvr.run(dev, world, rank, dist, with_cpu=not args.no_cpu, workload="head",
                                  dim=(128, 256, 256), size=(1920, 1080), cpu_rows=16, comm=comm)
 
+    pt_multi = None
+    if world > 1 and not args.no_pt:
+        from benchlib import bench_pt
+        pt_multi = bench_pt.run_multi(dev, world, rank, dist, comm=comm)
+
     if rank != 0:
         if dist:
             dist.destroy_process_group()
@@ -308,6 +313,9 @@ def main():
             c1 = bench_pt.config1_cpu()
             if c1:
                 out["config1_cpu_only"] = c1
+
+    if pt_multi:
+        out["path_trace"] = pt_multi
 
     # ---- volume path (reported beside the headline value) -------------------------------------------
     if dvr:

@@ -80,6 +80,95 @@ def run(dev: str, size=(1920, 1080), spp: int = 16, frames: int = 5, with_cpu: b
     return out
 
 
+def run_multi(dev: str, world: int, rank: int, dist, comm=None, size=(1920, 1080), spp: int = 16,
+              frames: int = 5) -> dict:
+    """The same frame shared between `world` ranks: rank 0 builds the tree and uploads the scene, both are
+    broadcast as one allocation each, every Render(Scene) call adds a sample to each rank's round-robin
+    16-row stripes (compact, accumulated per rank) and the RGBA8 stripes are gathered to rank 0 two calls
+    deep. Reports ms per frame of `spp` calls (max over ranks), the same without the gather, and whether
+    the gathered frame equals the frame rank 0 renders alone."""
+    from raytracer_amd import ray_tracer as rt
+    from raytracer_amd.lbvh import LBVH
+    from raytracer_amd.multi_gpu import StripeGatherer, broadcast_lbvh, broadcast_scene
+    path = os.path.join(ROOT, "tests", "golden", "veach_mis.npz")
+    if not os.path.exists(path):
+        return {}
+    d = dict(np.load(path))
+    W, H = size
+    if rank == 0:
+        tracer, arr, c, proj = make_tracer(d, W, H, dev)
+    else:  # an empty tracer and tree: both are filled by the broadcasts
+        from raytracer_amd.data.scene_setup import veach_camera
+        tracer = rt.RayTracer(dev)
+        tracer.SetWorldToScene(np.eye(4, dtype=np.float32))
+        tracer.SetLBVH(LBVH(dev))
+        tracer.SetMaxPathDepth(4)
+        c, proj = veach_camera(d, W, H)
+        tracer.SetProjection(proj)
+        tracer.SetCameraToWorld(c.pos, c.rotation())
+    torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    broadcast_lbvh(tracer.lbvh, src=0, comm=comm)
+    broadcast_scene(tracer, src=0, comm=comm)
+    torch.cuda.synchronize()
+    dist.barrier()
+    bcast_ms = (time.perf_counter() - t0) * 1e3
+    fb = FrameBuffer(W, H, dev)
+    g = StripeGatherer(W, H, world, rank, dev, dst=0, comm=comm)
+
+    def frame(gather=True):
+        tracer.curr_accu_spp = 1.0  # restart the accumulation
+        if tracer.d_accum is not None:
+            tracer.d_accum.zero_()  # the first sample's mean is prev + (c - prev) / 1: exact from zero only
+        for _ in range(spp):
+            if gather:
+                tracer.RenderGathered(fb, g)
+            else:
+                tracer.Render(fb, stripes=(rank, world), compact_out=g.send[0])
+
+    def timed(gather):
+        frame(gather)
+        g.flush(fb.rgba)
+        torch.cuda.synchronize()
+        dist.barrier()
+        t1 = time.perf_counter()
+        for _ in range(frames):
+            frame(gather)
+        if gather:
+            g.flush(fb.rgba)  # the last calls' gathers and their assembly on rank 0 are inside the time
+        torch.cuda.synchronize()
+        dist.barrier()
+        tt = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item()) * 1e3 / frames
+
+    ms = timed(True)
+    ms_render = timed(False)
+    frame(True)
+    g.flush(fb.rgba)
+    torch.cuda.synchronize()
+    dist.barrier()
+    same = None
+    if rank == 0:
+        got = fb.rgba.clone()
+        alone, _, _, _ = make_tracer(d, W, H, dev)
+        for _ in range(spp):
+            alone.Render(fb)
+        torch.cuda.synchronize()
+        same = bool(torch.equal(got, fb.rgba))
+    if rank != 0:
+        return {}
+    return {"workload": f"veach-mis {W}x{H}, {spp} spp, maxPathDepth 4, stripes of {world} GPUs gathered per call",
+            "n_gpus": world, "ms_per_frame": round(ms, 3), "render_only_ms_per_frame": round(ms_render, 3),
+            "gather_us_per_frame": round((ms - ms_render) * 1e3, 1),
+            "Mpaths_per_s": round(W * H * spp / (ms * 1e-3) / 1e6, 1),
+            "scene_and_tree_broadcast_ms": round(bcast_ms, 3),
+            "broadcast_bytes": int(tracer.lbvh.d_blob.numel() + tracer.d_scene_blob.numel()),
+            "gathered_frame_equals_single_gpu": same,
+            "transport": "kk_comm (library RCCL)" if comm is not None else f"torch.distributed/{dist.get_backend()}"}
+
+
 def config1_cpu(size=(512, 512), spp: int = 1) -> dict:
     """The first benchmark configuration as stated: the example scene, LBVH build + 512 x 512 path
     trace at 1 sample per pixel, the reference's logic (the CPU checker) on the host cores, no GPU."""

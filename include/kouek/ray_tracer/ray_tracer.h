@@ -42,14 +42,19 @@ class RayTracer : Noncopyable {
     bool modified = true;
     std::shared_ptr<LBVH> lbvh;
 
-    HIP::DeviceBuffer<Triangle> d_triangles;
-    HIP::DeviceBuffer<uvec3> d_triToPositionIndices;
-    HIP::DeviceBuffer<vec3> d_positions;
-    HIP::DeviceBuffer<vec3> d_normals;
-    HIP::DeviceBuffer<vec2> d_texCoords;
-    HIP::DeviceBuffer<Light> d_lights;
-    HIP::DeviceBuffer<Material> d_materials;
+    // The arrays SetMesh uploads (the reference's separate thrust vectors, ray_tracer.h:86-99) are pieces
+    // of one allocation (kk_pt_scene_blob_layout_of), so that Broadcast() is one collective.
+    HIP::DeviceBuffer<uint8_t> d_sceneBlob;
+    kk_pt_scene_sizes sceneSizes{};
+    kk_pt_scene_blob_layout sceneBlob{};
     HIP::DeviceBuffer<vec3> d_accuRndrTo;
+    // several GPUs: this rank's stripes (RGBA8 block that is sent, compact accumulation), root's receive blocks
+    HIP::DeviceBuffer<uint8_t> stripeSend, stripeBlocks;
+    HIP::DeviceBuffer<vec3> d_accuStripes;
+    struct StripeKey { // which shared frame the accumulation in d_accuStripes belongs to
+        int w = 0, h = 0, rank = -1, ranks = 0;
+        bool operator!=(const StripeKey &o) const { return w != o.w || h != o.h || rank != o.rank || ranks != o.ranks; }
+    } prevStripeKey;
     HIP::DeviceBuffer<uint8_t> d_traceTree; // the 8-wide tree the path tracer walks
 
     static constexpr std::string_view ErrTag = "[RayTracer Error]";
@@ -95,26 +100,43 @@ class RayTracer : Noncopyable {
                     break;
             tris[fi].grpIdx = gi - 1;
         }
-        d_triangles.assign(tris);
-        d_triToPositionIndices.assign(in.facePositionIndices);
-        d_positions.assign(in.positions);
-        d_normals.assign(in.normals);
-        d_texCoords.assign(in.texCoords);
-        d_lights.assign(in.lights);
-        d_materials.assign(in.materials);
-        scene.light_num = static_cast<IndexTy>(in.lights.size());
-        scene.triangles = reinterpret_cast<const kk_pt_triangle *>(d_triangles.data());
-        scene.tri_to_position_indices = reinterpret_cast<const uint32_t *>(d_triToPositionIndices.data());
-        scene.positions = reinterpret_cast<const float *>(d_positions.data());
-        scene.normals = reinterpret_cast<const float *>(d_normals.data());
-        scene.tex_coords = reinterpret_cast<const float *>(d_texCoords.data());
-        scene.lights = reinterpret_cast<const kk_light *>(d_lights.data());
-        scene.materials = reinterpret_cast<const kk_material *>(d_materials.data());
         float tot = 0.f;
         for (auto &lht : in.lights)
             tot += lht.area;
-        scene.light_tot_area = tot;
-        modified = true;
+        kk_pt_scene_sizes z{};
+        z.face_num = static_cast<uint32_t>(tris.size());
+        z.vert_num = static_cast<uint32_t>(in.positions.size());
+        z.normal_num = static_cast<uint32_t>(in.normals.size());
+        z.tex_coord_num = static_cast<uint32_t>(in.texCoords.size());
+        z.light_num = static_cast<uint32_t>(in.lights.size());
+        z.material_num = static_cast<uint32_t>(in.materials.size());
+        z.light_tot_area = tot;
+        if (!allocScene(z))
+            return;
+        static_assert(sizeof(Light) == sizeof(kk_light) && sizeof(Material) == sizeof(kk_material), "layout");
+        auto up = [&](uint64_t offs, const void *src, size_t bytes) {
+            return bytes == 0 || kk_memcpy_h2d(d_sceneBlob.data() + offs, src, bytes, nullptr) == KK_OK;
+        };
+        if (!(up(sceneBlob.triangles, tris.data(), sizeof(Triangle) * tris.size()) &&
+              up(sceneBlob.tri_to_position_indices, in.facePositionIndices.data(), 12ull * z.face_num) &&
+              up(sceneBlob.positions, in.positions.data(), 12ull * z.vert_num) &&
+              up(sceneBlob.normals, in.normals.data(), 12ull * z.normal_num) &&
+              up(sceneBlob.tex_coords, in.texCoords.data(), 8ull * z.tex_coord_num) &&
+              up(sceneBlob.lights, in.lights.data(), sizeof(Light) * in.lights.size()) &&
+              up(sceneBlob.materials, in.materials.data(), sizeof(Material) * in.materials.size())))
+            std::cerr << ErrTag << " " << kk_last_error() << "\n";
+    }
+    // Several GPUs (not part of the reference): what SetMesh uploaded on rank `root` reaches every rank of
+    // `comm` in two collectives - the sizes, then the scene's one allocation. The other ranks call no
+    // SetMesh; the tree travels by LBVH::Broadcast, and SetLBVH is called on every rank afterwards.
+    void Broadcast(const HIP::Communicator &comm, int root = 0) {
+        kk_pt_scene_sizes z = sceneSizes;
+        if (!KOUEK_HIP_CHECK(ErrTag.data(), kk_comm_broadcast_host(comm.Get(), &z, sizeof(z), root, nullptr)))
+            return;
+        if (comm.GetRank() != root && !allocScene(z))
+            return;
+        KOUEK_HIP_CHECK(ErrTag.data(), kk_pt_scene_broadcast(comm.Get(), d_sceneBlob.data(), &sceneSizes, root, nullptr));
+        kk_stream_synchronize(nullptr);
     }
     // Also builds the trace-side tree of `lbvh` (kk_trace_accel_build_with_leaf_boxes); the image is the same with
     // and without it, it only makes the hits cheaper to find.
@@ -218,6 +240,75 @@ class RayTracer : Noncopyable {
     }
 
     std::vector<vec3> ReadAccumulation() const { return d_accuRndrTo.to_host(); }
+
+    // Several GPUs (not part of the reference): one Render(Scene) call of a frame shared between the ranks
+    // of `comm`. Every rank adds the sample(s) to its round-robin 16-row stripes - straight into the block
+    // it sends, accumulated in a compact buffer of the same rows - the blocks are gathered on `root` and
+    // put back in image order in `rndrTo` there (other ranks pass any frame buffer of the size; theirs is
+    // left alone). A pixel's random stream is keyed by its place in the image, so the frame is the one
+    // Render() gives on one GPU, byte for byte. Blocking form of the exchange: one call, waited for.
+    void RenderGathered(HIP::FrameBuffer &rndrTo, const ivec2 &rndrSz, const HIP::Communicator &comm, int root = 0,
+                        int samples = 1) {
+        if (!lbvh || !lbvh->IsComplete()) {
+            std::cerr << ErrTag << " at " << __FILE__ << ":" << __LINE__ << ". lbvh is not set.\n";
+            return;
+        }
+        const int n = comm.GetRankNum(), r = comm.GetRank();
+        const size_t rows = static_cast<size_t>(kk_stripes_per_rank(rndrSz.y, n)) * 16;
+        const size_t blockBytes = rows * rndrSz.x * 4;
+        const StripeKey key{rndrSz.x, rndrSz.y, r, n};
+        bool needRedraw = modified || prevMaxSamplePerPixel != maxSamplePerPixel || prevStripeKey != key ||
+                          prevRndrTarget != RenderTarget::Scene || prevRndrTo != &rndrTo;
+        modified = false;
+        if (prevStripeKey != key || d_accuStripes.size() != rows * rndrSz.x) {
+            if (!d_accuStripes.resize(rows * rndrSz.x) || !stripeSend.resize(blockBytes) || !stripeSend.zero())
+                return;
+            if (r == root && !stripeBlocks.resize(blockBytes * n))
+                return;
+        }
+        if (needRedraw) {
+            currAccuSamplePerPixel = 1.f;
+            d_accuStripes.zero();
+        }
+        prevStripeKey = key;
+        prevRndrTo = &rndrTo;
+        prevRndrSz = ivec2{0, 0}; // a plain Render() afterwards starts over
+        prevRndrTarget = RenderTarget::Scene;
+        if (currAccuSamplePerPixel > maxSamplePerPixel)
+            return;
+        int cnt = samples < 1 ? 1 : samples;
+        const float left = maxSamplePerPixel - currAccuSamplePerPixel + 1.f;
+        if (static_cast<float>(cnt) > left)
+            cnt = static_cast<int>(left);
+        if (!KOUEK_HIP_CHECK(ErrTag.data(),
+                             kk_pt_render_stripes_compact(
+                                 reinterpret_cast<const kk_lbvh_device_data *>(lbvh->GetDeivceDataDevicePtr()), &scene,
+                                 &frame, reinterpret_cast<float *>(d_accuStripes.data()), stripeSend.data(), rndrSz.x,
+                                 rndrSz.y, r, n, currAccuSamplePerPixel, cnt, Seed, nullptr)))
+            return;
+        prevMaxSamplePerPixel = maxSamplePerPixel;
+        currAccuSamplePerPixel += static_cast<float>(cnt);
+        if (!KOUEK_HIP_CHECK(ErrTag.data(), kk_gather_stripes(comm.Get(), stripeSend.data(), stripeBlocks.data(),
+                                                              rndrSz.x, rndrSz.y, root, nullptr)))
+            return;
+        if (r == root)
+            KOUEK_HIP_CHECK(ErrTag.data(),
+                            kk_unstripe_rgba(stripeBlocks.data(), n, rndrSz.x, rndrSz.y, rndrTo.Get(), nullptr));
+        kk_stream_synchronize(nullptr);
+    }
+
+  private:
+    bool allocScene(const kk_pt_scene_sizes &z) {
+        sceneSizes = z;
+        if (!KOUEK_HIP_CHECK(ErrTag.data(), kk_pt_scene_blob_layout_of(&sceneSizes, &sceneBlob)) ||
+            !d_sceneBlob.resize(sceneBlob.total) ||
+            !KOUEK_HIP_CHECK(ErrTag.data(), kk_pt_scene_blob_bind(d_sceneBlob.data(), &sceneSizes, &scene))) {
+            std::cerr << ErrTag << " " << kk_last_error() << "\n";
+            return false;
+        }
+        modified = true;
+        return true;
+    }
 };
 
 } // namespace RayTracer

@@ -313,6 +313,19 @@ int kk_pt_render_samples(const kk_lbvh_device_data *d_lbvh, const kk_pt_scene *h
                          int height, int y0, int y1, float sample_index, int sample_count, uint32_t seed,
                          void *stream);
 
+/* The same samples for the 16-row stripes stripe_first, stripe_first + stripe_stride, ... of the image
+ * (stripe s = rows [16 s, 16 s + 16)): the share of one GPU when the frame is dealt out to several in
+ * round-robin stripes. The j-th stripe of the launch goes to rows [16 j, 16 j + 16) of the compact arrays
+ * d_accum_stripes float[kk_stripes_per_rank][16][W][3] and d_stripes uint8[...][16][W][4] - the latter is
+ * the block a rank hands to kk_gather_stripes; rows of a last, partial stripe beyond the image are not
+ * written. A pixel's random stream is keyed by its place in the image, so the block holds the bytes the
+ * same rows have after kk_pt_render_samples on one GPU. No counterpart in the reference, which renders on
+ * one GPU (ray_tracer_render.cu:579-638 is the work that is dealt out). */
+int kk_pt_render_stripes_compact(const kk_lbvh_device_data *d_lbvh, const kk_pt_scene *h_scene,
+                                 const kk_pt_frame *h_frame, float *d_accum_stripes, uint8_t *d_stripes,
+                                 int width, int height, int stripe_first, int stripe_stride,
+                                 float sample_index, int sample_count, uint32_t seed, void *stream);
+
 /* Diagnostics of the path-tracing kernel on the trace-side tree: while d_counters (uint64[16], zeroed by
  * the caller) is set, every kk_pt_render_sample adds [0] passes of the waves' walk loop, [1] lanes that
  * walked in them, [2] runs of a shading section, [3] lanes they ran for, [4] rays (closest-hit and
@@ -610,6 +623,26 @@ int kk_lbvh_blob_bind(void *d_blob, uint32_t face_num, uint32_t vert_num, void *
  * must be known on every rank (kk_comm_broadcast_host). */
 int kk_lbvh_broadcast(kk_comm *comm, void *d_blob, uint32_t face_num, uint32_t vert_num, int root,
                       void *stream);
+
+/* The arrays RayTracer::SetMesh uploads (src/ray_tracer/ray_tracer.cu:15-82) in ONE allocation, so that
+ * the scene travels beside the tree in one collective: triangles kk_pt_triangle[face_num],
+ * tri_to_position_indices uint32[face_num][3], positions float[vert_num][3], normals float[normal_num][3],
+ * tex_coords float[tex_coord_num][2], lights kk_light[light_num], materials kk_material[material_num],
+ * each 256-byte aligned. The sizes (32 bytes) must be known on every rank (kk_comm_broadcast_host). */
+typedef struct kk_pt_scene_sizes {
+    uint32_t face_num, vert_num, normal_num, tex_coord_num, light_num, material_num;
+    float light_tot_area;
+    uint32_t _pad;
+} kk_pt_scene_sizes;
+typedef struct kk_pt_scene_blob_layout {
+    uint64_t triangles, tri_to_position_indices, positions, normals, tex_coords, lights, materials, total;
+} kk_pt_scene_blob_layout;
+int kk_pt_scene_blob_layout_of(const kk_pt_scene_sizes *sizes, kk_pt_scene_blob_layout *out);
+/* Host-side: points h_io's seven array pointers into this blob and sets light_num / light_tot_area; the
+ * other fields of h_io (matrices, depth, trace tree) are left alone. */
+int kk_pt_scene_blob_bind(void *d_blob, const kk_pt_scene_sizes *sizes, kk_pt_scene *h_io);
+/* One collective over the blob. */
+int kk_pt_scene_broadcast(kk_comm *comm, void *d_blob, const kk_pt_scene_sizes *sizes, int root, void *stream);
 
 /* A Depth-Box VDB in one allocation: node pools, child pools, atlas map, atlas (256-byte aligned
  * pieces, sizes from the plan). */

@@ -67,6 +67,16 @@ class LbvhBlobLayout(C.Structure):
                                           "nodes", "total")]
 
 
+class PtSceneSizes(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("face_num", "vert_num", "normal_num", "tex_coord_num", "light_num",
+                                          "material_num")] + [("light_tot_area", C.c_float), ("_pad", C.c_uint32)]
+
+
+class PtSceneBlobLayout(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("triangles", "tri_to_position_indices", "positions", "normals",
+                                          "tex_coords", "lights", "materials", "total")]
+
+
 class VdbBlobLayout(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("node_pools", "child_pools", "atlas_map", "atlas", "total")]
 
@@ -115,6 +125,10 @@ def _declare(l):
     l.kk_closest_hit_accel.argtypes = [vp, u32, u32, vp, u32, vp, vp, vp, u32, vp, vp, sz, vp]
     l.kk_pt_render_sample.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, C.c_float, u32, vp]
     l.kk_pt_render_samples.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, C.c_float, i32, u32, vp]
+    l.kk_pt_render_stripes_compact.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, C.c_float, i32, u32, vp]
+    l.kk_pt_scene_blob_layout_of.argtypes = [vp, C.POINTER(PtSceneBlobLayout)]
+    l.kk_pt_scene_blob_bind.argtypes = [vp, vp, vp]
+    l.kk_pt_scene_broadcast.argtypes = [vp, vp, vp, i32, vp]
     l.kk_rt_render_target.argtypes = [vp, vp, vp, i32, vp, i32, i32, i32, i32, vp]
     l.kk_rng_uniforms.argtypes = [u32, u32, u32, u32, vp, vp]
     l.kk_stream_create.argtypes = [C.POINTER(vp)]

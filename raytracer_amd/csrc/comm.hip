@@ -139,6 +139,27 @@ __global__ void lbvh_bind_kernel(char *blob, LbvhBlob l) {
     dd->internal_nodes = reinterpret_cast<kk_lbvh_node *>(blob + l.nodes);
 }
 
+struct SceneBlob {
+    size_t triangles, triToPositionIndices, positions, normals, texCoords, lights, materials, total;
+};
+inline SceneBlob scene_blob(const kk_pt_scene_sizes &z) {
+    SceneBlob l;
+    Carver c;
+    l.triangles = c.take(sizeof(kk_pt_triangle) * static_cast<size_t>(z.face_num));
+    l.triToPositionIndices = c.take(12ull * z.face_num);
+    l.positions = c.take(12ull * z.vert_num);
+    l.normals = c.take(12ull * z.normal_num);
+    l.texCoords = c.take(8ull * z.tex_coord_num);
+    l.lights = c.take(sizeof(kk_light) * static_cast<size_t>(z.light_num));
+    l.materials = c.take(sizeof(kk_material) * static_cast<size_t>(z.material_num));
+    l.total = c.off;
+    return l;
+}
+inline bool scene_sizes_ok(const kk_pt_scene_sizes &z) {
+    return z.face_num > 0 && z.face_num <= KK_LBVH_MAX_FACES && z.vert_num > 0 && z.normal_num > 0 &&
+           z.material_num > 0;
+}
+
 struct VdbBlob {
     size_t nodes, children, atlasMap, atlas, total;
 };
@@ -307,6 +328,47 @@ extern "C" int kk_lbvh_broadcast(kk_comm *c, void *d_blob, uint32_t face_num, ui
     if (rc != KK_OK)
         return rc;
     return kk_lbvh_blob_bind(d_blob, face_num, vert_num, stream);
+}
+
+// ---- path tracer's scene blob ------------------------------------------------------------------------
+
+extern "C" int kk_pt_scene_blob_layout_of(const kk_pt_scene_sizes *sizes, kk_pt_scene_blob_layout *out) {
+    KK_REQUIRE(sizes && out, "null pointer");
+    KK_REQUIRE(scene_sizes_ok(*sizes), "sizes out of range");
+    const SceneBlob l = scene_blob(*sizes);
+    out->triangles = l.triangles;
+    out->tri_to_position_indices = l.triToPositionIndices;
+    out->positions = l.positions;
+    out->normals = l.normals;
+    out->tex_coords = l.texCoords;
+    out->lights = l.lights;
+    out->materials = l.materials;
+    out->total = l.total;
+    return KK_OK;
+}
+
+extern "C" int kk_pt_scene_blob_bind(void *d_blob, const kk_pt_scene_sizes *sizes, kk_pt_scene *h_io) {
+    KK_REQUIRE(d_blob && sizes && h_io, "null pointer");
+    KK_REQUIRE(scene_sizes_ok(*sizes), "sizes out of range");
+    const SceneBlob l = scene_blob(*sizes);
+    const char *b = static_cast<const char *>(d_blob);
+    h_io->triangles = reinterpret_cast<const kk_pt_triangle *>(b + l.triangles);
+    h_io->tri_to_position_indices = reinterpret_cast<const uint32_t *>(b + l.triToPositionIndices);
+    h_io->positions = reinterpret_cast<const float *>(b + l.positions);
+    h_io->normals = reinterpret_cast<const float *>(b + l.normals);
+    h_io->tex_coords = sizes->tex_coord_num ? reinterpret_cast<const float *>(b + l.texCoords) : nullptr;
+    h_io->lights = sizes->light_num ? reinterpret_cast<const kk_light *>(b + l.lights) : nullptr;
+    h_io->materials = reinterpret_cast<const kk_material *>(b + l.materials);
+    h_io->light_num = sizes->light_num;
+    h_io->light_tot_area = sizes->light_tot_area;
+    return KK_OK;
+}
+
+extern "C" int kk_pt_scene_broadcast(kk_comm *c, void *d_blob, const kk_pt_scene_sizes *sizes, int root,
+                                     void *stream) {
+    KK_REQUIRE(c && d_blob && sizes, "null pointer");
+    KK_REQUIRE(scene_sizes_ok(*sizes), "sizes out of range");
+    return kk_comm_broadcast(c, d_blob, scene_blob(*sizes).total, root, stream);
 }
 
 // ---- VDB blob ----------------------------------------------------------------------------------------

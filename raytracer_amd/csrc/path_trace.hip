@@ -278,7 +278,7 @@ template <bool WIDE>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(5, 5))) void path_trace_kernel(
     const kk_lbvh_device_data *__restrict__ lbvh, const accel::View view, const kk_pt_scene p,
     const kk_pt_frame f, float *__restrict__ accum, uint8_t *__restrict__ rgba, int W, int H, int y0, int y1,
-    float sampleIdx, uint32_t seed) {
+    float sampleIdx, uint32_t seed, int outRowShift) {
     // binary walk: one word per entry; wide walk: a group (base word + 16 bits) per entry
     constexpr int WORDS = WIDE ? accel::LANE_LDS_DEPTH : trav::STACK_DEPTH;
     __shared__ uint32_t s_stack[WORDS * THREADS];
@@ -339,17 +339,20 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(5, 5)))
         tracer.stride = THREADS;
         color = renderScene(tracer, p, rng, eyeRay);
     }
-    const f3 prev = {accum[3ull * idx], accum[3ull * idx + 1], accum[3ull * idx + 2]};
+    // image row y is row y - outRowShift of the output arrays (0 for a whole image; a stripe of a compact
+    // block sits outRowShift rows lower than in the image); the random stream stays keyed by the image pixel
+    const uint32_t odx = idx - static_cast<uint32_t>(outRowShift) * W;
+    const f3 prev = {accum[3ull * odx], accum[3ull * odx + 1], accum[3ull * odx + 2]};
     color = prev + (color - prev) / sampleIdx;
-    accum[3ull * idx] = color.x;
-    accum[3ull * idx + 1] = color.y;
-    accum[3ull * idx + 2] = color.z;
+    accum[3ull * odx] = color.x;
+    accum[3ull * odx + 1] = color.y;
+    accum[3ull * odx + 2] = color.z;
     uchar4 o;
     o.x = static_cast<uint8_t>(255.f * color.x);
     o.y = static_cast<uint8_t>(255.f * color.y);
     o.z = static_cast<uint8_t>(255.f * color.z);
     o.w = 255;
-    reinterpret_cast<uchar4 *>(rgba)[idx] = o;
+    reinterpret_cast<uchar4 *>(rgba)[odx] = o;
 }
 
 // ---- the frame as a persistent, compacting kernel (8-wide tree) ----------------------------------------
@@ -423,11 +426,15 @@ struct PathState {
 
 } // namespace persist
 
-template <bool COUNT, int WAVES>
+// STRIPES: the rows [y0, y1) are rows of a compact block of 16-row image stripes stripeFirst, stripeFirst +
+// stripeStride, ... (one GPU's share of a frame dealt out in round-robin stripes): row r of the block is
+// image row 16 (stripeFirst + (r / 16) stripeStride) + r % 16, accum / rgba are indexed by block row, and
+// the random stream is keyed by the image pixel as ever, so the block holds the bytes of those image rows.
+template <bool COUNT, int WAVES, bool STRIPES>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void path_trace_persistent_kernel(
     const accel::View view, const kk_pt_scene p, const kk_pt_frame f, float *__restrict__ accum,
     uint8_t *__restrict__ rgba, int W, int H, int y0, int y1, float sampleIdx, int sampleCount, uint32_t seed,
-    uint32_t *pixelQueue, unsigned long long *counters) {
+    uint32_t *pixelQueue, unsigned long long *counters, int stripeFirst, int stripeStride) {
     using namespace persist;
     using namespace accel;
     __shared__ uint32_t s_stack[LANE_LDS_DEPTH * THREADS];
@@ -462,6 +469,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(WAVES, 
     uint32_t stage = ST_IDLE;
     bool poolEmpty = false;
     PathState ps{};
+    uint32_t outPixel = 0u; // STRIPES: where the lane's pixel sits in the compact block
     RayState ray{};
     RaySigns sg{false, false, false, 0u};
     uint32_t mode = MODE_FAST;
@@ -733,7 +741,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(WAVES, 
                 Lo.x = powf(Lo.x, 1.f / 2.2f);
                 Lo.y = powf(Lo.y, 1.f / 2.2f);
                 Lo.z = powf(Lo.z, 1.f / 2.2f);
-                const uint32_t idx = ps.pixel;
+                const uint32_t idx = STRIPES ? outPixel : ps.pixel;
                 const f3 prev = {accum[3ull * idx], accum[3ull * idx + 1], accum[3ull * idx + 2]};
                 const f3 color = prev + (Lo - prev) / static_cast<float>(ps.sample);
                 accum[3ull * idx] = color.x;
@@ -770,8 +778,14 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(WAVES, 
                         const uint32_t tile = (q >> 6) * NQ + firstTile, in = q & 63u;
                         const uint32_t tx = tile % tilesX, ty = tile / tilesX;
                         const int x = static_cast<int>(tx * 8u + (in & 7u));
-                        const int y = y0 + static_cast<int>(ty * 8u + (in >> 3));
-                        if (x < W && y < y1) {
+                        int y = y0 + static_cast<int>(ty * 8u + (in >> 3));
+                        bool inside = x < W && y < y1;
+                        if (STRIPES) {
+                            outPixel = static_cast<uint32_t>(y) * W + x;
+                            y = ((stripeFirst + (y >> 4) * stripeStride) << 4) + (y & 15);
+                            inside = inside && y < H;
+                        }
+                        if (inside) {
                             ps.pixel = static_cast<uint32_t>(y) * W + x;
                             ps.sample = sampleFirst;
                             stage = ST_NEXT_SAMPLE;
@@ -900,14 +914,17 @@ static int persist_queue_ptr(uint32_t **out) {
 } // namespace pt
 } // namespace kk
 
-extern "C" int kk_pt_render_samples(const kk_lbvh_device_data *d_lbvh, const kk_pt_scene *h_scene,
-                                    const kk_pt_frame *h_frame, float *d_accum, uint8_t *d_rgba,
-                                    int width, int height, int y0, int y1, float sample_index,
-                                    int sample_count, uint32_t seed, void *stream_) {
-    using namespace kk;
-    using namespace kk::pt;
+namespace kk {
+namespace pt {
+
+// Rows [y0, y1) of the image (stripeStride == 0), or the 16-row stripes stripeFirst, stripeFirst +
+// stripeStride, ... written one after the other into compact arrays (stripeStride > 0).
+static int render_samples(const kk_lbvh_device_data *d_lbvh, const kk_pt_scene *h_scene,
+                          const kk_pt_frame *h_frame, float *d_accum, uint8_t *d_rgba, int width, int height,
+                          int y0, int y1, int stripeFirst, int stripeStride, float sample_index,
+                          int sample_count, uint32_t seed, void *stream_) {
     KK_REQUIRE(d_lbvh && h_scene && h_frame && d_accum && d_rgba, "null pointer");
-    KK_REQUIRE(width > 0 && height > 0 && y0 >= 0 && y1 <= height && y0 <= y1, "bad image size or rows");
+    KK_REQUIRE(width > 0 && height > 0, "bad image size");
     KK_REQUIRE(sample_index >= 1.f, "sample_index is 1-based");
     KK_REQUIRE(sample_count >= 1 && sample_count <= 65536 && sample_index < 16777216.f - 65536.f,
                "sample_count out of range");
@@ -915,9 +932,17 @@ extern "C" int kk_pt_render_samples(const kk_lbvh_device_data *d_lbvh, const kk_
                    h_scene->normals && h_scene->materials,
                "scene arrays missing");
     KK_REQUIRE(h_scene->light_num == 0 || h_scene->lights, "lights missing");
+    const bool stripes = stripeStride > 0;
+    int stripeNum = 0; // stripes of this launch
+    if (stripes) {
+        const int all = div_up(height, 16);
+        stripeNum = stripeFirst < all ? (all - stripeFirst + stripeStride - 1) / stripeStride : 0;
+        y0 = 0;
+        y1 = 16 * stripeNum; // rows of the compact block
+    }
     if (y0 == y1)
         return KK_OK;
-    dim3 grid(div_up(width, TILE_W), div_up(y1 - y0, TILE_H));
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (h_scene->trace_accel) {
         KK_REQUIRE(h_scene->accel_face_num > 0 && h_scene->accel_compacted_face_num > 0 &&
                        h_scene->accel_compacted_face_num <= h_scene->accel_face_num,
@@ -926,7 +951,6 @@ extern "C" int kk_pt_render_samples(const kk_lbvh_device_data *d_lbvh, const kk_
             accel::make_view(h_scene->trace_accel, h_scene->accel_face_num, h_scene->accel_compacted_face_num);
         // resident workgroups that pull pixels from a queue; the queue head is one of a ring of words
         // in the library's device image, cleared on this stream before the launch
-        hipStream_t stream = static_cast<hipStream_t>(stream_);
         uint32_t *queues = nullptr;
         const int rc = persist_queue_ptr(&queues);
         if (rc != KK_OK)
@@ -942,31 +966,71 @@ extern "C" int kk_pt_render_samples(const kk_lbvh_device_data *d_lbvh, const kk_
         if (pgrid > resident)
             pgrid = resident;
         unsigned long long *dbg = g_debugCounters.load();
-#define KK_LAUNCH_PT(COUNT, WAVES)                                                                    \
-    path_trace_persistent_kernel<COUNT, WAVES><<<pgrid, THREADS, 0, stream>>>(                           \
+#define KK_LAUNCH_PT(COUNT, WAVES, STRIPES)                                                           \
+    path_trace_persistent_kernel<COUNT, WAVES, STRIPES><<<pgrid, THREADS, 0, stream>>>(                  \
         view, *h_scene, *h_frame, d_accum, d_rgba, width, height, y0, y1, sample_index, sample_count, seed, \
-        head, dbg)
+        head, dbg, stripeFirst, stripeStride)
+#define KK_LAUNCH_PT2(COUNT, WAVES)                                                                   \
+    do {                                                                                               \
+        if (stripes)                                                                                   \
+            KK_LAUNCH_PT(COUNT, WAVES, true);                                                          \
+        else                                                                                           \
+            KK_LAUNCH_PT(COUNT, WAVES, false);                                                         \
+    } while (0)
         if (dbg) {
             if (longLaunch)
-                KK_LAUNCH_PT(true, persist::WAVES_LONG);
+                KK_LAUNCH_PT2(true, persist::WAVES_LONG);
             else
-                KK_LAUNCH_PT(true, persist::WAVES_SHORT);
+                KK_LAUNCH_PT2(true, persist::WAVES_SHORT);
         } else {
             if (longLaunch)
-                KK_LAUNCH_PT(false, persist::WAVES_LONG);
+                KK_LAUNCH_PT2(false, persist::WAVES_LONG);
             else
-                KK_LAUNCH_PT(false, persist::WAVES_SHORT);
+                KK_LAUNCH_PT2(false, persist::WAVES_SHORT);
         }
+#undef KK_LAUNCH_PT2
 #undef KK_LAUNCH_PT
     } else
-        for (int s = 0; s < sample_count; ++s) { // a launch per sample, in order
-            path_trace_kernel<false><<<grid, THREADS, 0, static_cast<hipStream_t>(stream_)>>>(
-                d_lbvh, accel::View{}, *h_scene, *h_frame, d_accum, d_rgba, width, height, y0, y1,
-                sample_index + static_cast<float>(s), seed);
-            KK_LAUNCH_CHECK();
+        for (int s = 0; s < sample_count; ++s) { // a launch per sample (and stripe), in order
+            const float si = sample_index + static_cast<float>(s);
+            if (!stripes) {
+                path_trace_kernel<false><<<dim3(div_up(width, TILE_W), div_up(y1 - y0, TILE_H)), THREADS, 0, stream>>>(
+                    d_lbvh, accel::View{}, *h_scene, *h_frame, d_accum, d_rgba, width, height, y0, y1, si, seed, 0);
+                KK_LAUNCH_CHECK();
+            } else
+                for (int j = 0; j < stripeNum; ++j) {
+                    const int r0 = 16 * (stripeFirst + j * stripeStride);
+                    const int r1 = r0 + 16 < height ? r0 + 16 : height;
+                    path_trace_kernel<false><<<dim3(div_up(width, TILE_W), 1), THREADS, 0, stream>>>(
+                        d_lbvh, accel::View{}, *h_scene, *h_frame, d_accum, d_rgba, width, height, r0, r1, si, seed,
+                        r0 - 16 * j);
+                    KK_LAUNCH_CHECK();
+                }
         }
     KK_LAUNCH_CHECK();
     return KK_OK;
+}
+
+} // namespace pt
+} // namespace kk
+
+extern "C" int kk_pt_render_samples(const kk_lbvh_device_data *d_lbvh, const kk_pt_scene *h_scene,
+                                    const kk_pt_frame *h_frame, float *d_accum, uint8_t *d_rgba,
+                                    int width, int height, int y0, int y1, float sample_index,
+                                    int sample_count, uint32_t seed, void *stream_) {
+    KK_REQUIRE(width > 0 && height > 0 && y0 >= 0 && y1 <= height && y0 <= y1, "bad image size or rows");
+    return kk::pt::render_samples(d_lbvh, h_scene, h_frame, d_accum, d_rgba, width, height, y0, y1, 0, 0,
+                                  sample_index, sample_count, seed, stream_);
+}
+
+extern "C" int kk_pt_render_stripes_compact(const kk_lbvh_device_data *d_lbvh, const kk_pt_scene *h_scene,
+                                            const kk_pt_frame *h_frame, float *d_accum_stripes,
+                                            uint8_t *d_stripes, int width, int height, int stripe_first,
+                                            int stripe_stride, float sample_index, int sample_count,
+                                            uint32_t seed, void *stream_) {
+    KK_REQUIRE(stripe_first >= 0 && stripe_stride > 0, "bad stripe selection");
+    return kk::pt::render_samples(d_lbvh, h_scene, h_frame, d_accum_stripes, d_stripes, width, height, 0, 0,
+                                  stripe_first, stripe_stride, sample_index, sample_count, seed, stream_);
 }
 
 extern "C" int kk_pt_render_sample(const kk_lbvh_device_data *d_lbvh, const kk_pt_scene *h_scene,

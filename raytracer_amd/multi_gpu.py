@@ -116,6 +116,22 @@ def broadcast_lbvh(bvh: LBVH, src: int = 0, comm: Communicator | None = None) ->
         bvh._complete = True
 
 
+def broadcast_scene(tracer, src: int = 0, comm: Communicator | None = None) -> None:
+    """Broadcasts what RayTracer.SetMesh uploaded - triangles, triangle-to-position indices, positions,
+    normals, texture coordinates, lights, materials - beside the tree: the sizes (32 bytes), then the
+    scene's one allocation in a single collective; every rank's scene struct points into its own copy."""
+    rank = comm.rank if comm is not None else dist.get_rank()
+    raw = bytes(C.sizeof(_lib.PtSceneSizes))
+    if rank == src:
+        raw = bytes(tracer.scene_sizes)
+    raw = _bcast_bytes(raw, src, tracer.device, comm)
+    if rank != src:
+        tracer.alloc_scene_blob(_lib.PtSceneSizes.from_buffer_copy(raw))
+        tracer.host_arrays = None
+    _bcast_tensor(tracer.d_scene_blob, src, comm)
+    tracer._modified = True
+
+
 def split_range(total: int, world: int, rank: int):
     """Contiguous share [begin, end) of `total` items for `rank`."""
     base, rem = divmod(total, world)

@@ -210,36 +210,82 @@ class RayTracer:
                      else stack_structs(materials, MATERIAL_DTYPE))
         assert lights.dtype.itemsize == 80 and materials.dtype.itemsize == 64, "struct layout lost"
 
-        def up(a, dtype=None):
-            a = np.ascontiguousarray(a)
-            return torch.from_numpy(a.view(np.uint8).reshape(-1).copy()).to(dev)
-
-        k = self._keep
-        k["triangles"], k["tri"] = up(tris), up(fpi)
-        k["positions"] = up(np.asarray(positions, np.float32))
-        k["normals"] = up(np.asarray(normals, np.float32))
-        k["tex_coords"] = up(np.asarray(tex_coords, np.float32)) if len(tex_coords) else up(np.zeros(2, np.float32))
-        k["lights"] = up(lights) if lights.size else None
-        k["materials"] = up(materials)
-        s = self._scene
-        s.triangles, s.tri_to_position_indices = k["triangles"].data_ptr(), k["tri"].data_ptr()
-        s.positions, s.normals = k["positions"].data_ptr(), k["normals"].data_ptr()
-        s.tex_coords, s.materials = k["tex_coords"].data_ptr(), k["materials"].data_ptr()
-        s.lights = k["lights"].data_ptr() if lights.size else None
-        s.light_num = int(lights.size)
+        sizes = _lib.PtSceneSizes()
+        sizes.face_num, sizes.vert_num = n, int(np.asarray(positions).reshape(-1, 3).shape[0])
+        sizes.normal_num = int(np.asarray(normals).reshape(-1, 3).shape[0])
+        sizes.tex_coord_num = int(np.asarray(tex_coords).reshape(-1, 2).shape[0]) if len(tex_coords) else 0
+        sizes.light_num, sizes.material_num = int(lights.size), int(materials.size)
         tot = np.float32(0)
         for a in lights["area"]:
             tot = np.float32(tot + a)
-        s.light_tot_area = float(tot)
+        sizes.light_tot_area = float(tot)
+        self.alloc_scene_blob(sizes)
+        k = self._keep
+
+        def up(name, a):
+            a = np.ascontiguousarray(a)
+            if a.size:
+                k[name].copy_(torch.from_numpy(a.view(np.uint8).reshape(-1).copy()))
+
+        up("triangles", tris), up("tri", fpi)
+        up("positions", np.asarray(positions, np.float32))
+        up("normals", np.asarray(normals, np.float32))
+        up("tex_coords", np.asarray(tex_coords, np.float32))
+        up("lights", lights), up("materials", materials)
         self.host_arrays = {"triangles": tris, "tri": fpi, "positions": np.asarray(positions, np.float32),
                             "normals": np.asarray(normals, np.float32), "lights": lights,
                             "materials": materials}
         self._modified = True
 
+    def alloc_scene_blob(self, sizes: "_lib.PtSceneSizes") -> None:
+        """The arrays of SetMesh live in one allocation (so that the scene travels to other GPUs in one
+        collective, kk_pt_scene_blob_layout_of); the scene struct's pointers point into it."""
+        lay = _lib.PtSceneBlobLayout()
+        _lib.check(_lib.lib().kk_pt_scene_blob_layout_of(C.byref(sizes), C.byref(lay)),
+                   "kk_pt_scene_blob_layout_of")
+        b = torch.zeros(int(lay.total), dtype=torch.uint8, device=self.device)
+        self.d_scene_blob, self.scene_sizes, self.scene_blob_layout = b, sizes, lay
+        piece = lambda off, nbytes: b[int(off):int(off) + nbytes]
+        self._keep = {"triangles": piece(lay.triangles, 32 * sizes.face_num),
+                      "tri": piece(lay.tri_to_position_indices, 12 * sizes.face_num),
+                      "positions": piece(lay.positions, 12 * sizes.vert_num),
+                      "normals": piece(lay.normals, 12 * sizes.normal_num),
+                      "tex_coords": piece(lay.tex_coords, 8 * sizes.tex_coord_num),
+                      "lights": piece(lay.lights, 80 * sizes.light_num),
+                      "materials": piece(lay.materials, 64 * sizes.material_num)}
+        _lib.check(_lib.lib().kk_pt_scene_blob_bind(b.data_ptr(), C.byref(sizes), C.byref(self._scene)),
+                   "kk_pt_scene_blob_bind")
+        self._modified = True
+
+    def scene_host_arrays(self) -> dict:
+        """The scene's arrays read back from its allocation, in the reference's struct layouts (what
+        SetMesh uploaded, or what a broadcast delivered)."""
+        # (np.frombuffer over the bytes: copying a struct array with explicit offsets field by field would
+        # not keep its padding bytes)
+        k = {n: t.cpu().numpy().tobytes() for n, t in self._keep.items()}
+        return {"triangles": np.frombuffer(k["triangles"], TRIANGLE_DTYPE),
+                "tri": np.frombuffer(k["tri"], np.uint32).reshape(-1, 3),
+                "positions": np.frombuffer(k["positions"], np.float32).reshape(-1, 3),
+                "normals": np.frombuffer(k["normals"], np.float32).reshape(-1, 3),
+                "tex_coords": np.frombuffer(k["tex_coords"], np.float32).reshape(-1, 2),
+                "lights": np.frombuffer(k["lights"], LIGHT_DTYPE),
+                "materials": np.frombuffer(k["materials"], MATERIAL_DTYPE)}
+
     use_trace_tree = True  # walk the 8-wide trace-side tree (same image); False: the binary tree as built
 
     def SetLBVH(self, lbvh: LBVH):
         self.lbvh = lbvh
+
+    def RenderGathered(self, fb: FrameBuffer, gatherer, samples: int = 1) -> None:
+        """Several GPUs (not part of the reference): one Render(Scene) call of a frame shared between the
+        ranks of `gatherer` (multi_gpu.StripeGatherer). Every rank adds the sample(s) to its round-robin
+        16-row stripes, straight into the block it sends; the gather is issued without waiting for it and
+        the frame of two calls ago is put together in fb on the gathering rank (gatherer.flush(fb.rgba)
+        brings the last ones in). The random stream is keyed by the image pixel, so the gathered frame is
+        the frame one GPU renders, byte for byte."""
+        buf = gatherer.begin(fb.rgba)
+        self.Render(fb, samples=samples, stripes=(gatherer.rank, gatherer.world), compact_out=buf)
+        gatherer.submit()
 
     def SetWorldToScene(self, w2s):
         self._set(self._scene, "w2s", w2s)
@@ -270,12 +316,17 @@ class RayTracer:
     RENDER_TARGETS = ("Scene", "AABBs", "Triangles", "Lights", "Positions", "Normals", "TextureCoords",
                       "None")
 
-    def Render(self, fb: FrameBuffer, rows=None, target: str = "Scene", samples: int = 1) -> None:
+    def Render(self, fb: FrameBuffer, rows=None, target: str = "Scene", samples: int = 1, stripes=None,
+               compact_out=None) -> None:
         """ray_tracer_render.cu:433-647. `target` is one of RENDER_TARGETS (RayTracer::RenderTarget);
         "Scene" path-traces and accumulates one sample, the others draw one inspection frame. `rows` =
         (y0, y1) restricts the call to a stripe of the image (multi-GPU tiling); the sample counter
         advances all the same. `samples` > 1 does the work of that many consecutive calls in one launch
-        (same image, bit for bit; never past maxSamplePerPixel)."""
+        (same image, bit for bit; never past maxSamplePerPixel). `stripes` = (first, stride) with
+        `compact_out` (uint8 tensor [per, 16, W, 4]) renders the 16-row stripes first, first + stride, ...
+        (one GPU's share of a frame dealt out to several) one after the other into compact_out - the block
+        a rank hands to the gathering rank - and accumulates them in a compact buffer of the same rows;
+        fb then only names the frame's size."""
         import sys
         if self.lbvh is None or not self.lbvh.IsComplete():
             print(f"{self.ErrTag} lbvh is not set.", file=sys.stderr)
@@ -294,11 +345,14 @@ class RayTracer:
             # like the reference, a switch of target restarts the accumulation of the next Scene call
             self._modified = True
             return
-        size = (fb.width, fb.height)
+        size = (fb.width, fb.height) + (tuple(int(v) for v in stripes) if stripes is not None else ())
         need_redraw = self._modified
         self._modified = False
         if self._prev_size != size or self.d_accum is None:
-            self.d_accum = torch.zeros((fb.height, fb.width, 3), dtype=torch.float32, device=self.device)
+            acc_rows = fb.height
+            if stripes is not None:
+                acc_rows = 16 * int(_lib.lib().kk_stripes_per_rank(fb.height, int(stripes[1])))
+            self.d_accum = torch.zeros((acc_rows, fb.width, 3), dtype=torch.float32, device=self.device)
         need_redraw |= (self._prev_max_spp != self.max_sample_per_pixel or self._prev_fb is not fb or
                         self._prev_size != size)
         if need_redraw:
@@ -315,10 +369,22 @@ class RayTracer:
             else:
                 self._scene.trace_accel = None
             n = int(min(max(int(samples), 1), self.max_sample_per_pixel - self.curr_accu_spp + 1))
-            _lib.check(_lib.lib().kk_pt_render_samples(
-                self.lbvh.GetDeivceDataDevicePtr(), C.byref(self._scene), C.byref(self._frame),
-                self.d_accum.data_ptr(), fb.rgba.data_ptr(), fb.width, fb.height, int(y0), int(y1),
-                C.c_float(self.curr_accu_spp), n, self.SEED, _lib.current_stream_ptr()),
-                "kk_pt_render_samples")
+            if stripes is not None:
+                if compact_out is None:
+                    raise ValueError("stripes need compact_out")
+                need = self.d_accum.shape[0] * fb.width * 4
+                if compact_out.numel() * compact_out.element_size() < need:
+                    raise _lib.KoukeError("compact_out is smaller than this rank's stripes")
+                _lib.check(_lib.lib().kk_pt_render_stripes_compact(
+                    self.lbvh.GetDeivceDataDevicePtr(), C.byref(self._scene), C.byref(self._frame),
+                    self.d_accum.data_ptr(), compact_out.data_ptr(), fb.width, fb.height, int(stripes[0]),
+                    int(stripes[1]), C.c_float(self.curr_accu_spp), n, self.SEED, _lib.current_stream_ptr()),
+                    "kk_pt_render_stripes_compact")
+            else:
+                _lib.check(_lib.lib().kk_pt_render_samples(
+                    self.lbvh.GetDeivceDataDevicePtr(), C.byref(self._scene), C.byref(self._frame),
+                    self.d_accum.data_ptr(), fb.rgba.data_ptr(), fb.width, fb.height, int(y0), int(y1),
+                    C.c_float(self.curr_accu_spp), n, self.SEED, _lib.current_stream_ptr()),
+                    "kk_pt_render_samples")
         self._prev_max_spp = self.max_sample_per_pixel
         self.curr_accu_spp += float(n)

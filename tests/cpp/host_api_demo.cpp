@@ -186,6 +186,18 @@ int main(int argc, char **argv) {
             // the tree is still the tree after its broadcast: one more sample on top
             tracer.Render(fb, sz);
             save(out + "/pt_accum_after_broadcast.f32", tracer.ReadAccumulation());
+            // the path-traced frame as a shared frame: the scene travels like the tree, every Render call
+            // is rendered as this rank's compact stripes, gathered and put back in image order
+            tracer.Broadcast(comm, 0);
+            tracer.SetLBVH(lbvh);
+            HIP::FrameBuffer pfb(sz);
+            tracer.RenderGathered(pfb, sz, comm, 0);
+            if (static_cast<int>(cam[30]) > 1)
+                tracer.RenderGathered(pfb, sz, comm, 0, static_cast<int>(cam[30]) - 1);
+            pfb.ReadBack(img);
+            save(out + "/pt_gathered_rgba.u8", img);
+            std::vector<float> gspp = {tracer.GetCurrentAccumulatedSamplePerPixel()};
+            save(out + "/pt_gathered_spp.f32", gspp);
         } else
             std::fprintf(stderr, "no RCCL on this machine: %s\n", kk_last_error());
     }

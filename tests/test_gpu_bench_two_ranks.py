@@ -30,6 +30,9 @@ def test_two_rank_rehearsal():
     # the frame put together from two ranks' stripes is the frame one GPU renders, byte for byte
     assert out["dvr"]["gathered_frame_equals_single_gpu"] is True
     assert out["dvr_head_1080p"]["gathered_frame_equals_single_gpu"] is True
+    # the path-traced frame shared between the two ranks: scene + tree broadcast, stripes gathered per call
+    assert out["path_trace"]["n_gpus"] == 2 and out["path_trace"]["ms_per_frame"] > 0
+    assert out["path_trace"]["gathered_frame_equals_single_gpu"] is True
     assert "gather_us_per_frame" in out["dvr"] and out["dvr"]["render_only_ms_per_frame"] > 0
     # ... and so is the last frame of the loop that keeps two frames in flight on every rank
     assert out["dvr"]["fps_two_frames_in_flight"] > 0

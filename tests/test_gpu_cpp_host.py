@@ -100,6 +100,10 @@ def test_cpp_host_classes_match_checker(oracle, veach, tmp_path):
                                 c.pos, c.rotation(), acc, img, float(spp + 1))
         got3 = np.fromfile(outd / "pt_accum_after_broadcast.f32", np.float32).reshape(H, W, 3)
         assert float((np.abs(got3 - acc).max(axis=2) > 1e-3).mean()) <= 2e-3
+        # RayTracer::Broadcast + RenderGathered: the frame of the plain Render calls, byte for byte
+        assert (np.fromfile(outd / "pt_gathered_rgba.u8", np.uint8).tobytes() ==
+                np.fromfile(outd / "pt_rgba.u8", np.uint8).tobytes())
+        assert float(np.fromfile(outd / "pt_gathered_spp.f32", np.float32)[0]) == spp + 1
     else:
         assert "no RCCL on this machine" in r.stderr
     # RAW-volume caster and two inspection targets through the C++ classes

@@ -248,3 +248,69 @@ def test_several_samples_in_one_launch_equal_separate_calls(veach):
     assert tracer2.GetCurrentAccumulatedSamplePerPixel() == 8
     tracer2.Render(fb2, samples=10)
     assert tracer2.GetCurrentAccumulatedSamplePerPixel() == 8
+
+
+@pytest.mark.parametrize("world,use_tree", [(2, True), (3, True), (2, False)])
+def test_compact_stripes_hold_the_rows_of_the_single_gpu_frame(veach, world, use_tree):
+    """What rank r of `world` GPUs renders - its round-robin 16-row stripes, compact, accumulated in a
+    compact buffer - is byte for byte the same rows of the frame one GPU renders: the random stream is
+    keyed by the image pixel. H is no multiple of 16 (last stripe partial); three samples, once as three
+    calls and once as one launch."""
+    from raytracer_amd import multi_gpu
+    W, H, spp = 200, 120 - 6, 3
+    tracer, arr, c, proj = _setup(veach, W, H)
+    tracer.use_trace_tree = use_tree
+    fb = FrameBuffer(W, H, DEV)
+    for _ in range(spp):
+        tracer.Render(fb)
+    torch.cuda.synchronize()
+    want_acc, want_img = tracer.d_accum.cpu().numpy(), fb.ReadBack()
+    per = multi_gpu.stripes_per_rank(H, world)
+    for batched in (False, True):
+        blocks = torch.zeros((world, per, 16, W, 4), dtype=torch.uint8, device=DEV)
+        for r in range(world):
+            t2, _, _, _ = _setup(veach, W, H)
+            t2.use_trace_tree = use_tree
+            if batched:
+                t2.Render(fb, samples=spp, stripes=(r, world), compact_out=blocks[r])
+            else:
+                for _ in range(spp):
+                    t2.Render(fb, stripes=(r, world), compact_out=blocks[r])
+            torch.cuda.synchronize()
+            assert t2.GetCurrentAccumulatedSamplePerPixel() == spp + 1
+            acc = t2.d_accum.cpu().numpy()
+            assert acc.shape == (16 * per, W, 3)
+            for j, s in enumerate(multi_gpu.stripes_of(H, world, r)):
+                rows = min(16, H - 16 * s)
+                assert acc[16 * j:16 * j + rows].tobytes() == want_acc[16 * s:16 * s + rows].tobytes()
+        out = torch.zeros((H, W, 4), dtype=torch.uint8, device=DEV)
+        multi_gpu.unstripe(blocks, world, out)
+        assert out.cpu().numpy().tobytes() == want_img.tobytes()
+
+
+def test_stated_size_of_the_second_configuration_matches_checker(oracle, veach):
+    """The example scene at 1920 x 1080 with 16 calls of Render(Scene) (the sequence of
+    app/rt_lbvh.cpp:239-296): a 16-row band through the lights and the floor is compared with the CPU
+    checker's accumulation of the same rows, within 1e-3 absolute."""
+    W, H, spp = 1920, 1080, 16
+    tracer, arr, c, proj = _setup(veach, W, H)
+    fb = FrameBuffer(W, H, DEV)
+    for _ in range(spp):
+        tracer.Render(fb)
+    torch.cuda.synchronize()
+    assert tracer.GetCurrentAccumulatedSamplePerPixel() == spp + 1
+    rows = (H // 2 - 8, H // 2 + 8)
+    b = oracle.lbvh_build(veach["positions"], veach["face_position_indices"])
+    acc = np.zeros((H, W, 3), np.float32)
+    img = np.zeros((H, W, 4), np.uint8)
+    for s in range(1, spp + 1):
+        oracle.pt_render_sample(b, arr, np.eye(4, dtype=np.float32), cam.inverse_projective(proj),
+                                c.pos, c.rotation(), acc, img, float(s), rows=rows)
+    got = tracer.d_accum[rows[0]:rows[1]].cpu().numpy()
+    ref = acc[rows[0]:rows[1]]
+    assert float(ref.max()) > 0.2, "the band shows nothing"
+    err = np.abs(got - ref).max(axis=2)
+    assert float((err > TOL).mean()) <= 2e-3
+    assert float(np.abs(got - ref).mean()) < 1e-4
+    gimg = fb.ReadBack()[rows[0]:rows[1]]
+    assert float((np.abs(gimg.astype(int) - img[rows[0]:rows[1]].astype(int)).max(axis=2) > 1).mean()) <= 2e-3

@@ -185,3 +185,53 @@ def test_library_communicator_one_rank():
     for i in range(len(orbits)):
         assert got2[i].tobytes() == want2[i].tobytes(), f"frame {i}"
     comm.close()
+
+
+@pytest.mark.parametrize("transport", ["torch", "capi"])
+def test_path_tracer_scene_broadcast_and_gathered_render(group, veach, transport):
+    """The path tracer's share of the N > 1 path with one rank: the scene's one allocation goes through a
+    broadcast, Render(Scene) calls run as RenderGathered (compact stripes, gather two frames deep) and the
+    frame that comes out is the frame of plain Render calls, byte for byte."""
+    from raytracer_amd import _lib, multi_gpu
+    from raytracer_amd.data.scene_setup import make_tracer
+    from raytracer_amd.ray_tracer import FrameBuffer
+    comm = None
+    if transport == "capi":
+        try:
+            comm = multi_gpu.Communicator(0, 1, DEV)
+        except _lib.KoukeError as e:
+            pytest.skip(f"RCCL communicator could not be created: {e}")
+    W, H, calls = 168, 100, 4  # the last stripe is partial
+    tracer, arr, c, proj = make_tracer(veach, W, H, DEV)
+    before = tracer.d_scene_blob.cpu().numpy().copy()
+    multi_gpu.broadcast_lbvh(tracer.lbvh, src=0, comm=comm)
+    multi_gpu.broadcast_scene(tracer, src=0, comm=comm)
+    torch.cuda.synchronize()
+    assert tracer.d_scene_blob.cpu().numpy().tobytes() == before.tobytes()
+    got_arr = tracer.scene_host_arrays()
+    assert got_arr["lights"].tobytes() == arr["lights"].tobytes()
+    assert got_arr["triangles"].tobytes() == arr["triangles"].tobytes()
+    plain, gathered = FrameBuffer(W, H, DEV), FrameBuffer(W, H, DEV)
+    want = []
+    for _ in range(calls):
+        tracer.Render(plain)
+        torch.cuda.synchronize()
+        want.append(plain.ReadBack().copy())
+    t2, _, _, _ = make_tracer(veach, W, H, DEV)
+    g = multi_gpu.StripeGatherer(W, H, 1, 0, DEV, comm=comm)
+    got = []
+    for i in range(calls):
+        t2.RenderGathered(gathered, g)
+        if i >= 2:  # the frame of two calls ago has just been put together
+            torch.cuda.synchronize()
+            got.append(gathered.ReadBack().copy())
+    for k in (g.slot, g.slot ^ 1):
+        g._wait(k, gathered.rgba)
+        torch.cuda.synchronize()
+        got.append(gathered.ReadBack().copy())
+    assert len(got) == calls
+    for a, b in zip(got, want):
+        assert a.tobytes() == b.tobytes()
+    assert (want[-1][..., :3].max(axis=2) > 0).mean() > 0.2
+    if comm is not None:
+        comm.close()

@@ -136,6 +136,57 @@ def _worker(rank, world, port, out_dir):
         assert (want[0][..., 3] > 0).mean() > 0.05
     else:
         g.flush()
+    # ---- path tracer: the scene's one allocation is broadcast, each rank path-traces its stripes with the
+    # checker from the arrays it RECEIVED, two Render(Scene) calls are gathered two frames deep ------------
+    from raytracer_amd.data.scene_setup import veach_arrays, veach_camera
+    from raytracer_amd.ray_tracer import RayTracer
+    veach = dict(np.load(os.path.join(ROOT, "tests", "golden", "veach_mis.npz")))
+    tracer = RayTracer("cpu")
+    if rank == 0:
+        arr0 = veach_arrays(veach)
+        tracer.SetMesh(veach["positions"], veach["normals"], veach["tex_coords"],
+                       veach["grp_start_face_indices"], veach["face_position_indices"],
+                       veach["face_normal_indices"], veach["face_tex_coord_indices"], arr0["lights"],
+                       arr0["materials"])
+    multi_gpu.broadcast_scene(tracer, src=0)
+    arr = tracer.scene_host_arrays()
+    want_arr = veach_arrays(veach)
+    for name in ("triangles", "lights", "materials"):
+        assert arr[name].tobytes() == want_arr[name].tobytes(), name
+    assert arr["positions"].tobytes() == veach["positions"].astype(np.float32).tobytes()
+    assert tracer._scene.light_num == 3 and tracer._scene.triangles == tracer._keep["triangles"].data_ptr()
+    assert tracer._scene.materials == tracer._keep["materials"].data_ptr()
+    tree = ko.lbvh_build(arr["positions"], arr["tri"])
+    PW, PH = 48, 50  # 4 stripes, the last one partial
+    c, proj = veach_camera(veach, PW, PH)
+    view = (np.eye(4, dtype=np.float32), cam.inverse_projective(proj), c.pos, c.rotation())
+    g = multi_gpu.StripeGatherer(PW, PH, world, rank, "cpu")
+    frame = torch.zeros((PH, PW, 4), dtype=torch.uint8)
+    acc = np.zeros((PH, PW, 3), np.float32)
+    img = np.zeros((PH, PW, 4), np.uint8)
+    got_frames = []
+    for sample in (1, 2, 3):
+        buf = g.begin(frame)
+        if g.frames >= 2 and rank == 0:
+            got_frames.append(frame.numpy().copy())
+        for j, s in enumerate(multi_gpu.stripes_of(PH, world, rank)):
+            rows = (16 * s, min(PH, 16 * s + 16))
+            ko.pt_render_sample(tree, arr, *view, acc, img, float(sample), rows=rows)
+            buf[j, :rows[1] - rows[0]] = torch.from_numpy(img[rows[0]:rows[1]])
+        g.submit()
+    if rank == 0:
+        for k in (g.slot, g.slot ^ 1):
+            g._wait(k, frame)
+            got_frames.append(frame.numpy().copy())
+        wacc = np.zeros((PH, PW, 3), np.float32)
+        wimg = np.zeros((PH, PW, 4), np.uint8)
+        for sample in (1, 2, 3):  # the frame one rank renders, call by call
+            ko.pt_render_sample(ko.lbvh_build(veach["positions"], veach["face_position_indices"]), want_arr,
+                                *view, wacc, wimg, float(sample))
+            assert got_frames[sample - 1].tobytes() == wimg.tobytes(), f"Render call {sample}"
+        assert (wimg[..., :3].max(axis=2) > 0).mean() > 0.2
+    else:
+        g.flush()
     # the blocking form over a frame rendered in place
     frame2 = torch.zeros((H, W, 4), dtype=torch.uint8)
     for s in multi_gpu.stripes_of(H, world, rank):
