@@ -127,6 +127,16 @@ class RayCaster : Noncopyable {
         adaptiveTileOrder = on;
         haveTileOrder = false;
     }
+    // Waits for `stream` and tells whether the sort behind the tile order of the last frame did its work
+    // (false, with the error printed: its look-back gave up; the library then keeps the launch order for
+    // the next frame, so every tile is still rendered and only the gain in frame time is lost).
+    bool CheckTileOrder(const HIP::Stream *stream = nullptr) {
+        if (!haveTileOrder)
+            return true;
+        return KOUEK_HIP_CHECK(ErrTag.data(),
+                               kk_dvr_tile_order_status(tileOrderWs.data(), static_cast<uint32_t>(tileCost.size()),
+                                                        stream ? stream->Get() : nullptr));
+    }
 
     // Several GPUs (not part of the reference): every rank of `comm` renders its round-robin 16-row
     // stripes of the Scene target straight into the block it sends, the blocks are gathered on rank

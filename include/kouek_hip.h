@@ -126,6 +126,21 @@ size_t kk_sort_workspace_error_offset(uint32_t n);
 int kk_sort_pairs_u32(uint32_t *d_keys_a, uint32_t *d_keys_b, uint32_t *d_vals_a, uint32_t *d_vals_b,
                       int vals_are_iota, uint32_t n, void *d_workspace, size_t workspace_bytes,
                       void *stream);
+/* Waits for `stream` and reads that word back: KK_ERR_DEVICE when the last sort of n keys with this
+ * workspace gave up (thrust::sort_by_key cannot fail this way; this sort's look-back can, see below). */
+int kk_sort_workspace_status(const void *d_workspace, uint32_t n, void *stream);
+/* How a tile of the sort (and of the LBVH build's run-head pass) finds its place in the chain of tiles.
+ * Off (the default): a tile is its workgroup's index. That leans on workgroups being started in index
+ * order, which holds for a grid that runs alone or beside kernels that do not wait on one another; two
+ * look-back grids that fill the GPU at the same time (sorts or builds on several streams) can in
+ * principle starve each other's tiles in front, which ends in the spin limit and the error word above.
+ * On: a tile takes a ticket from an atomic counter instead (about 12 us more per pass of 10 M keys),
+ * which holds whatever else runs. Callers that run sorts, LBVH builds, sorted closest-hit batches or
+ * tile-order sorts concurrently on one GPU should switch it on. Process-wide; returns the old value. */
+int kk_sort_set_ticketed(int on);
+/* Test hook: while on, every sort raises its error word when it is done, as a look-back that gave up
+ * would (the arrays it wrote are still sorted). Returns the old value. */
+int kk_debug_sort_force_error(int on);
 
 /* The same sort for callers that cannot allocate device memory (code under HIP graph capture, tight
  * serving loops, harnesses that forbid hipMalloc). No counterpart in the reference. It takes no
@@ -138,6 +153,12 @@ int kk_sort_pairs_u32(uint32_t *d_keys_a, uint32_t *d_keys_b, uint32_t *d_vals_a
 #define KK_SORT_STATIC_MAX_N (1u << 22)
 int kk_sort_pairs_u32_static(uint32_t *d_keys_a, uint32_t *d_keys_b, uint32_t *d_vals_a,
                              uint32_t *d_vals_b, int vals_are_iota, uint32_t n, void *stream);
+/* Looks up the current device's copy of that array (hipGetSymbolAddress, which may load the code
+ * object). kk_sort_pairs_u32_static does this by itself on its first call per device; a caller that
+ * will make that first call under HIP graph capture calls this once per device beforehand instead. */
+int kk_sort_static_init(void);
+/* The static sort's error word (see kk_sort_workspace_status) after the work queued on `stream`. */
+int kk_sort_static_status(void *stream);
 
 /* ================================================================================================
  * Path 1b: closest hit  --  rayCastLBVH<false> (src/ray_tracer/ray_tracer_render.cu:192-270)
@@ -222,6 +243,11 @@ int kk_closest_hit_accel(const void *d_accel, uint32_t face_num, uint32_t compac
                          const float *d_rays, uint32_t ray_num, float *d_t, float *d_bary,
                          uint32_t *d_prim, uint32_t flags, unsigned long long *d_counters,
                          void *d_workspace, size_t workspace_bytes, void *stream);
+/* Waits for `stream` and reports how the last kk_closest_hit_accel with this workspace ordered its
+ * rays: KK_ERR_DEVICE when the ray sort gave up (kk_sort_workspace_status). The kernel sees that too
+ * and then traces the rays in input order, so the hits are right either way; the status tells a caller
+ * that the call ran at the unsorted rate. */
+int kk_closest_hit_accel_status(const void *d_workspace, uint32_t ray_num, void *stream);
 
 /* ================================================================================================
  * Path 1c: path tracer  --  kouek::RayTracer::RayTracer::Render(surface, size, RenderTarget::Scene)
@@ -524,6 +550,10 @@ int kk_dvr_render_stripes_compact_ordered_u16(const kk_vdb_device_data *h_vdb, c
 size_t kk_dvr_tile_order_workspace_bytes(uint32_t tiles);
 int kk_dvr_tile_order(const uint32_t *d_tile_cost, uint32_t tiles, uint32_t *d_tile_order, void *d_workspace,
                       size_t workspace_bytes, void *stream);
+/* Waits for `stream` and reports on the last kk_dvr_tile_order with this workspace: KK_ERR_DEVICE when
+ * its sort gave up (kk_sort_workspace_status). d_tile_order then holds the launch order 0, 1, 2, ...
+ * (written on the stream after the sort), never a non-permutation, so no tile is left unrendered. */
+int kk_dvr_tile_order_status(const void *d_workspace, uint32_t tiles, void *stream);
 /* The same frame restricted to the 16-row stripes stripe_first, stripe_first + stripe_stride, ... of
  * the image (stripe s = rows [16 s, 16 s + 16)): the share of one GPU when the image is dealt out to
  * several in round-robin stripes. No counterpart in the reference, which renders on one GPU. */

@@ -109,6 +109,13 @@ def _declare(l):
     l.kk_sort_workspace_error_offset.restype = sz
     l.kk_sort_workspace_error_offset.argtypes = [u32]
     l.kk_sort_pairs_u32_static.argtypes = [vp, vp, vp, vp, i32, u32, vp]
+    l.kk_sort_workspace_status.argtypes = [vp, u32, vp]
+    l.kk_sort_static_status.argtypes = [vp]
+    l.kk_sort_static_init.argtypes = []
+    l.kk_sort_set_ticketed.argtypes = [i32]
+    l.kk_debug_sort_force_error.argtypes = [i32]
+    l.kk_closest_hit_accel_status.argtypes = [vp, u32, vp]
+    l.kk_dvr_tile_order_status.argtypes = [vp, u32, vp]
     l.kk_lbvh_workspace_layout.argtypes = [u32, u32, u32, C.POINTER(LbvhWsLayout)]
     l.kk_lbvh_build.argtypes = [vp, u32, vp, u32, vp, vp, vp, vp, vp, sz, u32, vp]
     l.kk_closest_hit_workspace_bytes.restype = sz

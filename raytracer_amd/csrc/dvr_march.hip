@@ -17,6 +17,7 @@
 #include "radix_hist.h"
 
 extern "C" size_t kk_sort_workspace_bytes(uint32_t n);
+extern "C" size_t kk_sort_workspace_error_offset(uint32_t n);
 
 namespace kk {
 namespace dvr {
@@ -1090,6 +1091,16 @@ __global__ __launch_bounds__(THREADS) void tile_keys_kernel(const uint32_t *__re
     rsort::hist_flush<1>(s_hist, ghist, threadIdx.x, THREADS);
 }
 
+// After the sort: an order made by a sort whose look-back gave up is no permutation of the tiles (tiles
+// would be left unrendered), so it is replaced by the launch order.
+__global__ __launch_bounds__(THREADS) void tile_order_fixup_kernel(const uint32_t *__restrict__ sortError,
+                                                                   uint32_t *__restrict__ order, uint32_t n) {
+    if (*sortError == 0u)
+        return;
+    for (uint32_t i = blockIdx.x * THREADS + threadIdx.x; i < n; i += gridDim.x * THREADS)
+        order[i] = i;
+}
+
 struct OrderWs {
     size_t keysA, keysB, sortWs, sortWsBytes, total;
 };
@@ -1133,8 +1144,32 @@ extern "C" int kk_dvr_tile_order(const uint32_t *d_tile_cost, uint32_t tiles, ui
     tile_keys_kernel<<<grid, THREADS, 0, stream>>>(d_tile_cost, tiles, keysA, ghist);
     KK_LAUNCH_CHECK();
     // one 8-bit pass from the A arrays (whose values are the tile numbers themselves) into the B arrays
-    return rsort::sort_pairs(keysA, reinterpret_cast<uint32_t *>(b + w.keysB), nullptr, d_tile_order, true, tiles,
-                             b + w.sortWs, w.sortWsBytes, stream, nullptr, 1, true);
+    uint32_t *sortError = nullptr;
+    const int rc2 = rsort::sort_pairs(keysA, reinterpret_cast<uint32_t *>(b + w.keysB), nullptr, d_tile_order, true,
+                                      tiles, b + w.sortWs, w.sortWsBytes, stream, &sortError, 1, true);
+    if (rc2 != KK_OK)
+        return rc2;
+    tile_order_fixup_kernel<<<grid, THREADS, 0, stream>>>(sortError, d_tile_order, tiles);
+    KK_LAUNCH_CHECK();
+    return KK_OK;
+}
+extern "C" int kk_dvr_tile_order_status(const void *d_workspace, uint32_t tiles, void *stream_) {
+    using namespace kk;
+    KK_REQUIRE(d_workspace != nullptr, "null pointer");
+    KK_REQUIRE(tiles > 0 && tiles <= KK_LBVH_MAX_FACES, "tile count out of range");
+    uint32_t word = 0;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    KK_HIP_TRY(hipMemcpyAsync(&word,
+                              static_cast<const char *>(d_workspace) + dvr::order_ws(tiles).sortWs +
+                                  kk_sort_workspace_error_offset(tiles),
+                              sizeof(word), hipMemcpyDeviceToHost, stream));
+    KK_HIP_TRY(hipStreamSynchronize(stream));
+    if (word != 0) {
+        set_error("kk_dvr_tile_order: the sort's look-back gave up (error word %u); the launch order was kept",
+                  word);
+        return KK_ERR_DEVICE;
+    }
+    return KK_OK;
 }
 #define KK_DVR_ORDERED(SUFFIX, TYPE)                                                                          \
     extern "C" int kk_dvr_render_ordered_##SUFFIX(                                                            \

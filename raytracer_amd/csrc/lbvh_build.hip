@@ -105,8 +105,10 @@ __global__ __launch_bounds__(THREADS) void build_setup_kernel(
     // words that later kernels of the build count in or poll start at zero
     for (uint32_t i = tid; i < headTiles; i += THREADS)
         headStatus[i] = 0u;
-    if (tid == 0)
-        *topCount = 0u;
+    if (tid == 0) {
+        topCount[0] = 0u;
+        topCount[1] = 0u; // the run-head pass's ticket counter (ticketed mode)
+    }
     float mn[3] = {FloatMax, FloatMax, FloatMax};
     float mx[3] = {FloatMin, FloatMin, FloatMin};
     for (uint32_t b = tid; b < partialNum; b += THREADS) {
@@ -225,7 +227,8 @@ __global__ __launch_bounds__(THREADS) void morton_kernel(const float *__restrict
 // and compaction in one pass over the keys. A tile of HEADS_TILE keys counts its heads, publishes the
 // count, adds up the counts of the tiles in front (a wave reads 64 of their status words per round trip
 // and stops at the first that already holds an inclusive count) and writes its heads. A tile is its
-// workgroup's index, as in the sort (radix_sort.hip): workgroups start in index order.
+// workgroup's index, as in the sort (radix_sort.hip): workgroups start in index order. TICKET: the tile
+// is a ticket from an atomic counter instead (kk_sort_set_ticketed).
 constexpr int HEADS_ITEMS = 16;
 constexpr int HEADS_TILE = THREADS * HEADS_ITEMS;
 constexpr uint32_t HEADS_AGG = 1u << 30, HEADS_INC = 2u << 30, HEADS_FLAGS = 3u << 30, HEADS_VALUE = ~HEADS_FLAGS;
@@ -241,15 +244,21 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan_u32(uint32_t v, int lane
     return v;
 }
 
+template <bool TICKET>
 __global__ __launch_bounds__(THREADS) void heads_kernel(const uint32_t *__restrict__ keys, uint32_t n,
                                                         uint32_t *tileStatus, uint32_t *__restrict__ compacted,
                                                         uint32_t *__restrict__ uniq, kk_lbvh_device_data *out,
-                                                        uint32_t *errorFlag) {
+                                                        uint32_t *errorFlag, uint32_t *ticket) {
     __shared__ uint32_t s_w[THREADS / 64];
     __shared__ uint32_t s_base;
     __shared__ uint32_t s_index[HEADS_TILE], s_code[HEADS_TILE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t tile = blockIdx.x;
+    if (TICKET) {
+        if (tid == 0)
+            s_base = atomicAdd(ticket, 1u);
+        __syncthreads();
+    }
+    const uint32_t tile = TICKET ? s_base : blockIdx.x; // (s_base is written again after the next barrier)
     // thread t owns the keys [first, first + HEADS_ITEMS)
     const uint32_t first = tile * HEADS_TILE + tid * HEADS_ITEMS;
     uint32_t k[HEADS_ITEMS];
@@ -898,7 +907,7 @@ inline Ws layout(uint32_t N, uint32_t flags) {
     w.pub.node_parents = c.take(4 * n);
     w.pub.leaf_parents = c.take(4 * n);
     w.headStatus = c.take(4 * static_cast<size_t>(w.headTiles));
-    w.topCount = c.take(4);
+    w.topCount = c.take(8); // the refit's list length; the run-head pass's ticket counter
     w.nodeInfo = c.take(8 * n);
     w.topList = c.take(4 * n);
     w.totals = c.take(24 * totals_layout(N).boxes);
@@ -987,8 +996,14 @@ extern "C" int kk_lbvh_build(const float *d_positions, uint32_t vert_num,
     if (rc != KK_OK)
         return rc;
 
-    heads_kernel<<<w.headTiles, THREADS, 0, stream>>>(keys0, N, headStatus, d_compacted, uniq, d_out,
-                                                       reinterpret_cast<uint32_t *>(b + w.pub.error_flag));
+    if (rsort::ticketed())
+        heads_kernel<true><<<w.headTiles, THREADS, 0, stream>>>(keys0, N, headStatus, d_compacted, uniq, d_out,
+                                                                 reinterpret_cast<uint32_t *>(b + w.pub.error_flag),
+                                                                 topCount + 1);
+    else
+        heads_kernel<false><<<w.headTiles, THREADS, 0, stream>>>(keys0, N, headStatus, d_compacted, uniq, d_out,
+                                                                  reinterpret_cast<uint32_t *>(b + w.pub.error_flag),
+                                                                  topCount + 1);
     KK_LAUNCH_CHECK();
 
     const uint32_t ngrid = div_up(N, KARRAS_THREADS);

@@ -24,6 +24,9 @@ int sort_pairs(uint32_t *keysA, uint32_t *keysB, uint32_t *valsA, uint32_t *vals
                void *ws, size_t wsBytes, hipStream_t stream, uint32_t **errorFlagOut, int passes,
                bool prepared = false);
 
+// Ticketed mode (kk_sort_set_ticketed): tiles take tickets instead of being their workgroup's index.
+bool ticketed();
+
 // lds: DIGITS * 256 words of the workgroup's LDS
 template <int DIGITS> __device__ __forceinline__ void hist_clear(uint32_t *lds, int tid, int threads) {
     for (int i = tid; i < DIGITS * HIST_RADIX; i += threads)

@@ -4,7 +4,9 @@
 //
 // One pass, per 4096-key tile (256 threads = 4 waves, 16 keys per lane):
 //   1. the tile is the workgroup's index: workgroups start in index order, so every lower-numbered
-//      tile has already started and the look-back below cannot wait on a tile that is not running;
+//      tile has already started and the look-back below cannot wait on a tile that is not running
+//      (or, in ticketed mode - kk_sort_set_ticketed - a ticket from an atomic counter, which does not
+//      lean on the start order and is what sorts that run beside other grids should use);
 //   2. each wave ranks its 1024 keys among equal digits with eight 64-lane ballots per key
 //      (match-any) and a per-wave digit counter in LDS;
 //   3. thread d owns digit d: sums the four wave counters, publishes the tile's count for the digit
@@ -17,6 +19,7 @@
 #include "kk_host.h"
 #include "radix_hist.h"
 
+#include <atomic>
 #include <mutex>
 
 namespace kk {
@@ -107,11 +110,11 @@ __global__ __launch_bounds__(THREADS) void histogram_kernel(const uint32_t *__re
     }
 }
 
-template <bool IOTA>
+template <bool IOTA, bool TICKET>
 __global__ __launch_bounds__(THREADS) void onesweep_pass_kernel(
     const uint32_t *__restrict__ keysIn, const uint32_t *__restrict__ valsIn,
     uint32_t *__restrict__ keysOut, uint32_t *__restrict__ valsOut, uint32_t n, uint32_t shift,
-    const uint32_t *__restrict__ ghist, uint32_t *tileStatus, uint32_t *errorFlag) {
+    const uint32_t *__restrict__ ghist, uint32_t *tileStatus, uint32_t *errorFlag, uint32_t *ticket) {
     __shared__ uint32_t s_keys[TILE];
     __shared__ uint32_t s_vals[TILE];
     __shared__ uint32_t s_whist[WAVES][RADIX];
@@ -122,6 +125,8 @@ __global__ __launch_bounds__(THREADS) void onesweep_pass_kernel(
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
 
+    if (TICKET && tid == 0)
+        s_tmp[0] = atomicAdd(ticket, 1u);
     for (int i = tid; i < WAVES * RADIX; i += THREADS)
         (&s_whist[0][0])[i] = 0;
     __syncthreads();
@@ -130,9 +135,11 @@ __global__ __launch_bounds__(THREADS) void onesweep_pass_kernel(
     // takes its share in order) and all ask for the same resources, so none is passed over. (A ticket
     // from an atomic counter would not lean on that order, but 2 442 returning atomics on one word cost
     // 12 us per pass at 10 M keys.) Should the order ever not hold, the spin limit ends the wait and
-    // raises the error word.
-    const uint32_t tile = blockIdx.x;
-    const uint32_t tileBase = tile * TILE;
+    // raises the error word. TICKET: the tile is the order in which the workgroups got here instead; a
+    // workgroup that holds a ticket runs, so every tile in front of it runs or is done, whatever else
+    // shares the GPU.
+    const uint32_t tile = TICKET ? s_tmp[0] : blockIdx.x;
+    const uint32_t tileBase = tile * TILE; // (s_tmp is written again only after the next barrier)
 
     // 1. load: wave w owns keys [tileBase + 1024 w, +1024), item i of lane l is key 64 i + l of those
     uint32_t key[ITEMS], val[ITEMS];
@@ -265,6 +272,14 @@ __global__ __launch_bounds__(THREADS) void onesweep_pass_kernel(
     }
 }
 
+// Test hook: raises the error word as a look-back that gave up would.
+__global__ void raise_error_kernel(uint32_t *errorFlag) { atomicOr(errorFlag, 2u); }
+
+static std::atomic<int> g_ticketed{0};
+static std::atomic<int> g_forceError{0};
+
+bool ticketed() { return g_ticketed.load(std::memory_order_relaxed) != 0; }
+
 struct SortWs {
     size_t ghist, counters, error, status, total;
     uint32_t tiles;
@@ -275,7 +290,7 @@ inline SortWs sort_ws(uint32_t n) {
     Carver c;
     w.tiles = div_up(n, TILE);
     w.ghist = c.take(sizeof(uint32_t) * HIST_COPIES * HIST_COPY_STRIDE);
-    w.counters = c.take(sizeof(uint32_t) * PASSES); // unused (tile tickets once); keeps the error word's offset
+    w.counters = c.take(sizeof(uint32_t) * PASSES); // the passes' ticket counters (ticketed mode)
     w.error = c.take(sizeof(uint32_t));
     w.status = c.take(sizeof(uint32_t) * PASSES * static_cast<size_t>(w.tiles) * RADIX);
     w.total = c.off;
@@ -311,6 +326,8 @@ int sort_pairs(uint32_t *keysA, uint32_t *keysB, uint32_t *valsA, uint32_t *vals
     uint32_t *ghist = reinterpret_cast<uint32_t *>(b + w.ghist);
     uint32_t *error = reinterpret_cast<uint32_t *>(b + w.error);
     uint32_t *status = reinterpret_cast<uint32_t *>(b + w.status);
+    uint32_t *tickets = reinterpret_cast<uint32_t *>(b + w.counters);
+    const bool ticketed = rsort::ticketed();
     if (errorFlagOut)
         *errorFlagOut = error;
     if (!prepared) {
@@ -326,12 +343,21 @@ int sort_pairs(uint32_t *keysA, uint32_t *keysB, uint32_t *valsA, uint32_t *vals
     uint32_t *kin = keysA, *kout = keysB, *vin = valsA, *vout = valsB;
     for (int p = 0; p < passes; ++p) {
         uint32_t *st = status + static_cast<size_t>(p) * w.tiles * RADIX;
-        if (p == 0 && iota)
-            onesweep_pass_kernel<true><<<w.tiles, THREADS, 0, stream>>>(
-                kin, nullptr, kout, vout, n, 8u * p, ghist + p * RADIX, st, error);
-        else
-            onesweep_pass_kernel<false><<<w.tiles, THREADS, 0, stream>>>(
-                kin, vin, kout, vout, n, 8u * p, ghist + p * RADIX, st, error);
+#define KK_LAUNCH_PASS(IOTA, TICKET)                                                               \
+    onesweep_pass_kernel<IOTA, TICKET><<<w.tiles, THREADS, 0, stream>>>(                           \
+        kin, (IOTA) ? nullptr : vin, kout, vout, n, 8u * p, ghist + p * RADIX, st, error, tickets + p)
+        if (p == 0 && iota) {
+            if (ticketed)
+                KK_LAUNCH_PASS(true, true);
+            else
+                KK_LAUNCH_PASS(true, false);
+        } else {
+            if (ticketed)
+                KK_LAUNCH_PASS(false, true);
+            else
+                KK_LAUNCH_PASS(false, false);
+        }
+#undef KK_LAUNCH_PASS
         KK_LAUNCH_CHECK();
         uint32_t *t = kin;
         kin = kout;
@@ -340,11 +366,40 @@ int sort_pairs(uint32_t *keysA, uint32_t *keysB, uint32_t *valsA, uint32_t *vals
         vin = vout;
         vout = t;
     }
+    if (g_forceError.load(std::memory_order_relaxed) != 0) {
+        raise_error_kernel<<<1, 1, 0, stream>>>(error);
+        KK_LAUNCH_CHECK();
+    }
     return KK_OK;
 }
 
 } // namespace rsort
 } // namespace kk
+
+extern "C" int kk_sort_set_ticketed(int on) { return kk::rsort::g_ticketed.exchange(on ? 1 : 0); }
+extern "C" int kk_debug_sort_force_error(int on) { return kk::rsort::g_forceError.exchange(on ? 1 : 0); }
+
+// The word a look-back raises when it gives up, read back after the work queued on `stream`:
+// KK_ERR_DEVICE when it is set (the arrays the sort wrote are then no permutation of its input).
+static int sort_error_status(const uint32_t *d_error, void *stream_, const char *what) {
+    uint32_t word = 0;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    KK_HIP_TRY(hipMemcpyAsync(&word, d_error, sizeof(word), hipMemcpyDeviceToHost, stream));
+    KK_HIP_TRY(hipStreamSynchronize(stream));
+    if (word != 0) {
+        kk::set_error("%s: the radix sort's look-back gave up waiting for a tile in front (error word %u); "
+                      "its output is not a permutation of its input", what, word);
+        return KK_ERR_DEVICE;
+    }
+    return KK_OK;
+}
+extern "C" int kk_sort_workspace_status(const void *d_workspace, uint32_t n, void *stream) {
+    KK_REQUIRE(d_workspace != nullptr, "null pointer");
+    KK_REQUIRE(n > 0, "n out of range");
+    return sort_error_status(reinterpret_cast<const uint32_t *>(static_cast<const char *>(d_workspace) +
+                                                                kk::rsort::sort_ws(n).error),
+                             stream, "kk_sort_pairs_u32");
+}
 
 extern "C" size_t kk_sort_workspace_bytes(uint32_t n) { return kk::rsort::sort_ws(n).total; }
 extern "C" size_t kk_sort_workspace_error_offset(uint32_t n) { return kk::rsort::sort_ws(n).error; }
@@ -405,6 +460,22 @@ extern "C" int kk_sort_pairs_u32_static(uint32_t *d_keys_a, uint32_t *d_keys_b, 
     // sort_pairs clears the part of the scratch it uses (histograms, counters, status rows) first
     return sort_pairs(d_keys_a, d_keys_b, d_vals_a, d_vals_b, vals_are_iota != 0, n, ws,
                       STATIC_SCRATCH_BYTES, static_cast<hipStream_t>(stream), nullptr, PASSES);
+}
+
+extern "C" int kk_sort_static_init(void) {
+    void *ws = nullptr;
+    return kk::rsort::scratch_ptr(&ws);
+}
+
+extern "C" int kk_sort_static_status(void *stream) {
+    void *ws = nullptr;
+    const int rc = kk::rsort::scratch_ptr(&ws);
+    if (rc != KK_OK)
+        return rc;
+    // the error word's place does not depend on n (sort_ws: histograms, counters, error, status rows)
+    return sort_error_status(reinterpret_cast<const uint32_t *>(static_cast<const char *>(ws) +
+                                                                kk::rsort::sort_ws(1).error),
+                             stream, "kk_sort_pairs_u32_static");
 }
 
 extern "C" int kk_sort_pairs_u32(uint32_t *d_keys_a, uint32_t *d_keys_b, uint32_t *d_vals_a,

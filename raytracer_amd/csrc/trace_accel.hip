@@ -43,6 +43,7 @@
 
 namespace kk {
 extern "C" size_t kk_sort_workspace_bytes(uint32_t n);
+extern "C" size_t kk_sort_workspace_error_offset(uint32_t n);
 
 namespace accel {
 
@@ -725,7 +726,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(5, 5)))
     const float *__restrict__ rays, const uint32_t *__restrict__ order, uint32_t rayNum,
     float *__restrict__ tOut, float *__restrict__ baryOut, uint32_t *__restrict__ primOut,
     uint32_t *rayCounter, const uint32_t *__restrict__ parents,
-    uint2 *__restrict__ spill, unsigned long long *counters) {
+    uint2 *__restrict__ spill, unsigned long long *counters, const uint32_t *sortError, uint32_t *status) {
     // groups waiting to be entered: childBase + (pending slots | internal-slot mask << 8)
     __shared__ uint32_t s_base[LDS_DEPTH * THREADS];
     __shared__ unsigned short s_bits[LDS_DEPTH * THREADS];
@@ -735,6 +736,14 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(5, 5)))
     unsigned short *stBits = s_bits + tid;
     const size_t spillStride = static_cast<size_t>(gridDim.x) * THREADS;
     uint2 *mySpill = spill + static_cast<size_t>(blockIdx.x) * THREADS + tid;
+    // A ray sort whose look-back gave up leaves an order that is no permutation of the rays: the rays are
+    // then traced in input order (the order only decides how fast, not what is found) and the call's
+    // status word says so.
+    const uint32_t sortFailed = (order != nullptr && sortError != nullptr) ? *sortError : 0u;
+    if (sortFailed != 0u)
+        order = nullptr;
+    if (blockIdx.x == 0 && tid == 0)
+        *status = sortFailed;
     const kk_lbvh_node *nodes = hdr->nodes;
     const char *wideBytes = reinterpret_cast<const char *>(wide);
 
@@ -822,6 +831,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(5, 5)))
                 if (rel < qLen && rel >= base) {
                     const uint32_t r = qBegin + rel;
                     rayIdx = order ? order[r] : r;
+                    rayIdx = rayIdx < rayNum ? rayIdx : rayNum - 1u; // (an order kept from other rays)
                     const float *p = rays + 6ull * rayIdx;
                     prepare_ray(F3(p[0], p[1], p[2]), F3(p[3], p[4], p[5]), ray, sg, mode);
                     if (WATERTIGHT)
@@ -978,7 +988,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(5, 5)))
 }
 
 struct TraceWs {
-    size_t counter, spill, keysA, keysB, valsA, valsB, sortWs, sortWsBytes, total;
+    size_t counter, spill, keysA, keysB, valsA, valsB, sortWs, sortWsBytes, status, total;
 };
 inline TraceWs trace_ws(uint32_t rayNum) {
     TraceWs w;
@@ -993,6 +1003,7 @@ inline TraceWs trace_ws(uint32_t rayNum) {
     w.counter = c.take(4 * QUEUES * QUEUE_STRIDE);
     w.sortWsBytes = kk_sort_workspace_bytes(static_cast<uint32_t>(n));
     w.sortWs = c.take(w.sortWsBytes);
+    w.status = c.take(4); // what the last call's kernel saw in the sort's error word
     w.total = c.off;
     return w;
 }
@@ -1124,6 +1135,24 @@ extern "C" size_t kk_closest_hit_accel_workspace_bytes(uint32_t ray_num) {
     return kk::accel::trace_ws(ray_num).total;
 }
 
+extern "C" int kk_closest_hit_accel_status(const void *d_workspace, uint32_t ray_num, void *stream_) {
+    using namespace kk;
+    KK_REQUIRE(d_workspace != nullptr, "null pointer");
+    if (ray_num == 0)
+        return KK_OK;
+    uint32_t word = 0;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    KK_HIP_TRY(hipMemcpyAsync(&word, static_cast<const char *>(d_workspace) + accel::trace_ws(ray_num).status,
+                              sizeof(word), hipMemcpyDeviceToHost, stream));
+    KK_HIP_TRY(hipStreamSynchronize(stream));
+    if (word != 0) {
+        set_error("kk_closest_hit_accel: the ray sort's look-back gave up (error word %u); the rays were traced "
+                  "in input order instead (same hits, slower)", word);
+        return KK_ERR_DEVICE;
+    }
+    return KK_OK;
+}
+
 extern "C" int kk_closest_hit_accel(const void *d_accel, uint32_t face_num,
                                     uint32_t compacted_face_num,
                                     const float *d_rays, uint32_t ray_num, float *d_t, float *d_bary,
@@ -1177,6 +1206,10 @@ extern "C" int kk_closest_hit_accel(const void *d_accel, uint32_t face_num,
             return rc;
         order = (KEY_PASSES & 1) ? valsB : valsA;
     }
+    // (with KK_TRACE_REUSE_ORDER the word is still the one of the sort that made the order)
+    const uint32_t *sortError =
+        order ? reinterpret_cast<const uint32_t *>(b + w.sortWs + kk_sort_workspace_error_offset(ray_num)) : nullptr;
+    uint32_t *status = reinterpret_cast<uint32_t *>(b + w.status);
     uint32_t grid = div_up(ray_num, THREADS);
     const uint32_t resident = GROUPS_PER_CU * static_cast<uint32_t>(device_cu_count());
     if (grid > resident)
@@ -1189,7 +1222,7 @@ extern "C" int kk_closest_hit_accel(const void *d_accel, uint32_t face_num,
 #define KK_LAUNCH_TRACE(COUNT, WT)                                                                 \
     closest_hit_accel_kernel<COUNT, WT><<<grid, THREADS, 0, stream>>>(                              \
         hdr, wide, recs, d_rays, order, ray_num, d_t, d_bary, d_prim, rayCounter, parents, spill,  \
-        d_counters)
+        d_counters, sortError, status)
     if (d_counters) {
         if (wt)
             KK_LAUNCH_TRACE(true, true);

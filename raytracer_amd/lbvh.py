@@ -138,6 +138,7 @@ class LBVH:
         l = _lib.lib()
         self._host_dd = None
         self._accel_stale = True  # the trace-side repacking describes the previous tree
+        self._accel_checked = None  # ... and its depth check too: depth follows the geometry, not (N, M)
         with torch.cuda.device(self.device):
             _lib.check(l.kk_lbvh_build(self.d_positions.data_ptr(), self.d_positions.shape[0],
                                        self.d_face_pos_idx.data_ptr(), self.face_num,

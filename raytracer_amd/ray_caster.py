@@ -78,6 +78,18 @@ class RayCaster:
                 st["ws"].numel(), stream), "kk_dvr_tile_order")
         st["have"] = True
 
+    def CheckTileOrder(self) -> None:
+        """Waits for the current stream and raises KoukeError when the sort behind the adaptive tile
+        order of the launch rendered last gave up (the library then keeps the launch order for the next
+        frame, so every tile is still rendered; only the frame-time gain is lost)."""
+        st = self._tile_state
+        if st is None or not st["have"]:
+            return
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().kk_dvr_tile_order_status(st["ws"].data_ptr(), st["n"],
+                                                           _lib.current_stream_ptr()),
+                       "kk_dvr_tile_order_status")
+
     @staticmethod
     def _fill(arr, value):
         for i, x in enumerate(np.asarray(value, np.float32).reshape(-1)):

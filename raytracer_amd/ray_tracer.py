@@ -11,15 +11,27 @@ from . import _lib
 from .lbvh import LBVH
 
 
+def closest_hit_status(workspace, ray_num: int) -> None:
+    """Waits for the current stream and raises KoukeError when the last closest_hit(layout="trace") call
+    with this workspace (the fourth entry of its `out`) found its ray sort had given up: the hits are
+    right all the same (the kernel then traces in input order), the call ran at the unsorted rate."""
+    with torch.cuda.device(workspace.device):
+        _lib.check(_lib.lib().kk_closest_hit_accel_status(workspace.data_ptr(), int(ray_num),
+                                                          _lib.current_stream_ptr()),
+                   "kk_closest_hit_accel_status")
+
+
 def closest_hit(lbvh: LBVH, rays, count: bool = False, out=None, layout: str = "trace", sort: bool = True,
-                reuse_order: bool = False, watertight: bool = False):
+                reuse_order: bool = False, watertight: bool = False, check: bool = False):
     """Traces rays [R,6] (pos, dir) through a built LBVH with rayCastLBVH<false>'s result semantics
     (src/ray_tracer/ray_tracer_render.cu:192-270). Returns torch tensors (t [R], bary [R,2],
     prim [R] int32 with -1 = miss) and, when `count`, a dict of work counters.
     layout "trace" walks the repacked two-box records (rays in Morton order unless sort=False);
     layout "build" walks the build's own 32-byte nodes. Both give the same hits. reuse_order keeps the
     ray order found by the previous call with the same `out` workspace (same rays). watertight swaps the
-    triangle test for the watertight one (trace layout only; hits may differ on grazing rays)."""
+    triangle test for the watertight one (trace layout only; hits may differ on grazing rays). check
+    waits for the call and raises if its ray sort gave up (closest_hit_status; a loop that must not
+    synchronise per call passes its own `out` and asks once at the end)."""
     l = _lib.lib()
     dev = lbvh.device
     d_rays = rays if isinstance(rays, torch.Tensor) else torch.from_numpy(
@@ -56,6 +68,8 @@ def closest_hit(lbvh: LBVH, rays, count: bool = False, out=None, layout: str = "
                                         _lib.KK_TRAVERSE_ORDERED,
                                         counters.data_ptr() if count else None, ws.data_ptr(), ws.numel(),
                                         _lib.current_stream_ptr()), "kk_closest_hit")
+    if check and layout == "trace":
+        closest_hit_status(ws, R)
     if count:
         c = counters.cpu().numpy()
         return t, bary, prim, {"node_fetches": int(c[0]), "tri_tests": int(c[1]), "rays": int(c[2]),

@@ -37,19 +37,28 @@ def _sort_static(keys, vals=None):
     l = _lib.lib()
     n = keys.shape[0]
     ka, kb, va, vb = _buffers(keys, vals)  # inputs and outputs are still the caller's
+    # the array's address is looked up (and the code object loaded) outside the measured call, as a caller
+    # under graph capture would do it
+    _lib.check(l.kk_sort_static_init(), "kk_sort_static_init")
     torch.cuda.synchronize()
+    # free device memory as the driver reports it (hipMemGetInfo): a hipMalloc inside the library would
+    # show here, which torch's own allocator statistics would not see
+    free_before, _ = torch.cuda.mem_get_info()
     before = torch.cuda.memory_allocated()
     _lib.check(l.kk_sort_pairs_u32_static(ka.data_ptr(), kb.data_ptr(), va.data_ptr(), vb.data_ptr(),
                                           1 if vals is None else 0, n, _lib.current_stream_ptr()),
                "kk_sort_pairs_u32_static")
     torch.cuda.synchronize()
     assert torch.cuda.memory_allocated() == before
+    assert torch.cuda.mem_get_info()[0] == free_before
+    _lib.check(l.kk_sort_static_status(_lib.current_stream_ptr()), "kk_sort_static_status")
     return ka.cpu().numpy().view(np.uint32), va.cpu().numpy().view(np.uint32)
 
 
 def test_static_sort_equals_workspace_sort_twice_in_a_row():
     rng = np.random.default_rng(2024)
     # the first call fills many status rows; the second, smaller one runs over their leftovers
+    _sort_static(np.arange(4096, dtype=np.uint32)[::-1].copy())  # (first launch: the runtime's own set-up)
     for n, with_vals in ((3_000_001, False), (70_003, True), (MAX_N, False), (1, False)):
         keys = rng.integers(0, 1 << 30, n, dtype=np.uint64).astype(np.uint32)
         keys[::7] = keys[0]  # duplicates: stability shows
