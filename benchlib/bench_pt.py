@@ -46,12 +46,26 @@ def run(dev: str, size=(1920, 1080), spp: int = 16, frames: int = 5, with_cpu: b
         torch.cuda.synchronize()
         return ev0.elapsed_time(ev1) / frames
 
+    # the trace-side repacking of this scene's tree (it has run nodes, which the soup's has not)
+    bvh = tracer.lbvh
+    for _ in range(2):
+        bvh.trace_accel(rebuild=True)
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for _ in range(10):
+        bvh.trace_accel(rebuild=True)
+    ev1.record()
+    torch.cuda.synchronize()
+    accel_ms = ev0.elapsed_time(ev1) / 10
+
     ms = timed(False)           # the reference's loop: one sample per Render call
     ms_batched = timed(True)    # the same image from one call (Render(fb, samples=spp))
     frame(False)
     out = {"workload": f"veach-mis {W}x{H}, {spp} spp, maxPathDepth 4",
            "ms_per_frame": round(ms, 3), "ms_per_sample_pass": round(ms / spp, 4),
            "ms_per_frame_one_call": round(ms_batched, 3),
+           "trace_accel_build_ms": round(accel_ms, 4),
            "Mpaths_per_s": round(W * H * spp / (ms * 1e-3) / 1e6, 1)}
     if with_cpu:
         from oracle import kkoracle as ko

@@ -627,6 +627,9 @@ typedef struct kk_comm kk_comm;
  * socket); every rank then calls kk_comm_init with its own GPU current (kk_set_device). */
 int kk_comm_unique_id(void *h_id /* KK_COMM_ID_BYTES */);
 int kk_comm_init(int nranks, int rank, const void *h_id, kk_comm **out);
+/* Waits for everything queued on the communicator's device (collectives may still be in flight on
+ * side streams) before it frees the communicator. The kk_comm_* calls that issue work fail with
+ * KK_ERR_INVALID when the current device is not the one the communicator was made on. */
 int kk_comm_destroy(kk_comm *comm);
 int kk_comm_rank(const kk_comm *comm, int *rank, int *nranks);
 /* One collective over `bytes` of device memory, enqueued on `stream`. */

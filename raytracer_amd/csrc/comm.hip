@@ -224,12 +224,32 @@ extern "C" int kk_comm_init(int nranks, int rank, const void *h_id, kk_comm **ou
     return KK_OK;
 }
 
+// The communicator belongs to the device that was current at kk_comm_init: its collectives run on that
+// device's streams and its staging buffer lives there.
+static int on_own_device(const kk_comm *c) {
+    int dev = -1;
+    KK_HIP_TRY(hipGetDevice(&dev));
+    if (dev != c->device) {
+        set_error("the communicator was made on device %d, the current device is %d", c->device, dev);
+        return KK_ERR_INVALID;
+    }
+    return KK_OK;
+}
+
 extern "C" int kk_comm_destroy(kk_comm *c) {
     if (!c)
         return KK_OK;
+    // collectives issued on any stream of the communicator's device may still be in flight (a gather on
+    // a side stream): they finish before the communicator and its staging buffer go away
+    int prev = -1;
+    const bool switched = hipGetDevice(&prev) == hipSuccess && prev != c->device &&
+                          hipSetDevice(c->device) == hipSuccess;
+    (void)hipDeviceSynchronize();
     if (c->d_stage)
         (void)hipFree(c->d_stage);
     ncclResult_t r = g_api.CommDestroy(c->comm);
+    if (switched)
+        (void)hipSetDevice(prev);
     delete c;
     if (r != ncclSuccess) {
         set_error("ncclCommDestroy failed: %s", g_api.GetErrorString(r));
@@ -252,6 +272,8 @@ extern "C" int kk_comm_broadcast(kk_comm *c, void *d_buf, size_t bytes, int root
     KK_REQUIRE(root >= 0 && root < c->nranks, "root out of range");
     if (bytes == 0)
         return KK_OK;
+    if (const int rc = on_own_device(c); rc != KK_OK)
+        return rc;
     KK_NCCL_TRY(g_api.Broadcast(d_buf, d_buf, bytes, ncclUint8, root, c->comm, static_cast<hipStream_t>(stream)));
     return KK_OK;
 }
@@ -260,6 +282,8 @@ extern "C" int kk_comm_broadcast_host(kk_comm *c, void *h_buf, size_t bytes, int
     KK_REQUIRE(c && h_buf, "null pointer");
     KK_REQUIRE(bytes <= 4096, "at most 4096 bytes");
     KK_REQUIRE(root >= 0 && root < c->nranks, "root out of range");
+    if (const int rc = on_own_device(c); rc != KK_OK)
+        return rc;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (c->rank == root)
         KK_HIP_TRY(hipMemcpyAsync(c->d_stage, h_buf, bytes, hipMemcpyHostToDevice, stream));
@@ -276,6 +300,8 @@ extern "C" int kk_comm_gather(kk_comm *c, const void *d_send, void *d_recv, size
     KK_REQUIRE(c->rank != root || d_recv != nullptr, "the root needs a receive buffer");
     if (bytes_per_rank == 0)
         return KK_OK;
+    if (const int rc = on_own_device(c); rc != KK_OK)
+        return rc;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (c->rank == root) {
         // the root's own block is a local copy; the others arrive over one link each

@@ -59,6 +59,7 @@ struct alignas(256) BuildCtl {
     // bound by their number, not by the work.
     uint32_t triCount, wideCount;
     uint32_t bounds[MAX_LEVELS + 2]; // wide nodes of level l are [bounds[l], bounds[l + 1])
+    uint32_t runCount;               // run nodes listed so far (Layout::runList)
 };
 
 // A leaf of the LBVH is a run of triangles with one Morton code; in a scene whose triangles are small
@@ -72,7 +73,7 @@ constexpr uint32_t LINKS_IN_NODE = 0xFFFFFFFFu; // collapse: a subtree slot whos
 constexpr uint32_t RUN_FLAG = 0x40000000u;          // rootOf: low bits = leaf index instead of a binary node
 
 struct Layout {
-    size_t header, ctl, nodes, tris, parents, rootOf, leafParent, recSrc, total;
+    size_t header, ctl, nodes, tris, parents, rootOf, leafParent, recSrc, runList, total;
     uint32_t wideMax;
 };
 inline Layout layout(uint32_t faceNum, uint32_t compactedNum) {
@@ -92,6 +93,8 @@ inline Layout layout(uint32_t faceNum, uint32_t compactedNum) {
     // build scratch: (sorted position, leaf's parent) of every triangle record. The padded leaf boxes,
     // 24 B per leaf, borrow the triangle records' own space, which is written last.
     l.recSrc = c.take(sizeof(uint2) * static_cast<size_t>(faceNum));
+    // the wide nodes that are run nodes, listed as they are reserved
+    l.runList = c.take(sizeof(uint32_t) * (static_cast<size_t>(faceNum - compactedNum) / (SPLIT_MIN - 1) + 1));
     l.total = c.off;
     return l;
 }
@@ -112,6 +115,7 @@ __global__ void init_build_kernel(const kk_lbvh_device_data *__restrict__ lbvh, 
     hdr->tooDeep = 0;
     ctl->wideCount = 1;
     ctl->triCount = 0;
+    ctl->runCount = 0;
     for (int l = 0; l < MAX_LEVELS + 2; ++l)
         ctl->bounds[l] = l == 0 ? 0u : 1u;
     rootOf[0] = 0;
@@ -301,6 +305,7 @@ struct CollapseArgs {
     uint32_t *rootOf;
     uint32_t *leafParent;
     BuildCtl *ctl;
+    uint32_t *runList;
 };
 __device__ __forceinline__ void collapse_range(CollapseLds &lds, const CollapseArgs &args, uint32_t start,
                                                uint32_t end, uint32_t group, uint32_t groups) {
@@ -491,6 +496,7 @@ __device__ __forceinline__ void collapse_range(CollapseLds &lds, const CollapseA
             if (splits(len)) { // the slot keeps the leaf's box; its triangles hang one node further down
                 rootOf[childBase + rank] = RUN_FLAG | (ref & LEAF_MASK);
                 leafParent[ref & LEAF_MASK] = s_aux[j][tid];
+                args.runList[atomicAdd(&ctl->runCount, 1u)] = childBase + rank;
                 ++rank;
                 continue;
             }
@@ -513,101 +519,167 @@ __device__ __forceinline__ void collapse_range(CollapseLds &lds, const CollapseA
     }
 }
 
-// The run nodes, after the last level (a thread per wide node; the few that are run nodes work): the
-// leaf's triangles in the order of their centres along the longest axis of those, cut into up to eight
-// chunks of equal length, each with the box of its own triangles.
-__global__ __launch_bounds__(BT) void run_nodes_kernel(CollapseArgs args, const Header *__restrict__ hdr) {
-    __shared__ SlotBoxes s_q;
-    const int tid = threadIdx.x;
-    const uint32_t w = blockIdx.x * BT + tid;
-    if (w >= hdr->wideNum)
-        return;
-    const uint32_t root = args.rootOf[w];
-    if (!(root & RUN_FLAG))
+// The run nodes, after the last level: the leaf's triangles in the order of their centres along the
+// longest axis of those (stable; -0 counts as +0, NaN keys last), cut into up to eight chunks of equal
+// length, each with the box of its own triangles. The collapse listed the run nodes as it reserved them;
+// a wave takes one run node at a time: two triangles per lane (a run has
+// at most SPLIT_MAX = 120), corners and keys kept in LDS, a triangle's place found by counting the keys
+// in front of it, the chunk boxes folded by one lane per chunk in the order of the chunk's triangles.
+constexpr int RUN_WAVES = BT / 64;
+constexpr int RUN_CAP = 128; // triangle slots of a wave (>= SPLIT_MAX, two per lane)
+static_assert(SPLIT_MAX <= RUN_CAP, "two triangles per lane");
+constexpr uint32_t RUN_GRID = 256; // 1024 waves share the list
+__global__ __launch_bounds__(BT) void run_nodes_kernel(CollapseArgs args) {
+    __shared__ SlotBoxes s_q; // column 64 * wave is the wave's
+    __shared__ float s_corner[RUN_WAVES][9][RUN_CAP];
+    __shared__ uint32_t s_key[RUN_WAVES][RUN_CAP];
+    __shared__ uint32_t s_order[RUN_WAVES][RUN_CAP]; // triangle (within the run) at each place of the order
+    __shared__ uint32_t s_chunkOut[RUN_WAVES][8];    // where a chunk's records start, relative to triBase
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t listed = args.ctl->runCount;
+    if (blockIdx.x * RUN_WAVES >= listed)
         return;
     const kk_lbvh_device_data *__restrict__ lbvh = args.lbvh;
     const uint32_t *__restrict__ faces = lbvh->faces;
-    const uint32_t leaf = root & ~RUN_FLAG, leafNum = lbvh->compacted_face_num;
-    const uint32_t k0 = lbvh->compacted_faces[leaf];
-    const uint32_t k1 = leaf == leafNum - 1 ? lbvh->face_num : lbvh->compacted_faces[leaf + 1];
-    const uint32_t n = k1 - k0; // SPLIT_MIN .. SPLIT_MAX
-    const uint32_t parent = args.leafParent[leaf];
-    const uint32_t triBase = args.out[w].triBase;
+    const uint32_t leafNum = lbvh->compacted_face_num;
     const float pad = leaf_pad(lbvh->internal_nodes);
-    const float *lb = args.leafBoxes + 6ull * leaf;
-    const QFrame fr = make_frame(F3(lb[0], lb[1], lb[2]), F3(lb[3], lb[4], lb[5]), pad);
-    auto corner = [&](uint32_t i, int c) {
-        return trav::load_pos(args.positions, args.tri[3ull * faces[k0 + i] + c]);
+    const int col = wave * 64; // this wave's column of s_q
+    float(*corner)[RUN_CAP] = s_corner[wave];
+    uint32_t *keys = s_key[wave], *order = s_order[wave], *chunkOut = s_chunkOut[wave];
+    auto wave_sync = []() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
-    f3 cLo = F3(__builtin_inff()), cHi = F3(-__builtin_inff());
-    for (uint32_t i = 0; i < n; ++i) {
-        const f3 c = corner(i, 0) + corner(i, 1) + corner(i, 2);
-        for (int a = 0; a < 3; ++a) {
-            cLo[a] = fminf(cLo[a], c[a]);
-            cHi[a] = fmaxf(cHi[a], c[a]);
+    for (uint32_t e = blockIdx.x * RUN_WAVES + wave; e < listed; e += gridDim.x * RUN_WAVES) { // (uniform over the wave)
+        const uint32_t w = args.runList[e];
+        const uint32_t leaf = args.rootOf[w] & ~RUN_FLAG;
+        const uint32_t k0 = lbvh->compacted_faces[leaf];
+        const uint32_t k1 = leaf == leafNum - 1 ? lbvh->face_num : lbvh->compacted_faces[leaf + 1];
+        const uint32_t n = k1 - k0; // SPLIT_MIN .. SPLIT_MAX
+        const uint32_t parent = args.leafParent[leaf];
+        const uint32_t triBase = args.out[w].triBase;
+        const float *lb = args.leafBoxes + 6ull * leaf;
+        const QFrame fr = make_frame(F3(lb[0], lb[1], lb[2]), F3(lb[3], lb[4], lb[5]), pad);
+        // corners into LDS; the sums of a triangle's corners (three times its centre) stay in registers
+        f3 sum[2];
+        f3 cLo = F3(__builtin_inff()), cHi = F3(-__builtin_inff());
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const uint32_t i = lane + 64u * h;
+            sum[h] = F3(0.f);
+            if (i < n) {
+                const uint32_t fi = faces[k0 + i];
+                const f3 a = trav::load_pos(args.positions, args.tri[3ull * fi]);
+                const f3 b = trav::load_pos(args.positions, args.tri[3ull * fi + 1]);
+                const f3 c = trav::load_pos(args.positions, args.tri[3ull * fi + 2]);
+                corner[0][i] = a.x, corner[1][i] = a.y, corner[2][i] = a.z;
+                corner[3][i] = b.x, corner[4][i] = b.y, corner[5][i] = b.z;
+                corner[6][i] = c.x, corner[7][i] = c.y, corner[8][i] = c.z;
+                sum[h] = a + b + c;
+                for (int ax = 0; ax < 3; ++ax) {
+                    cLo[ax] = fminf(cLo[ax], sum[h][ax]);
+                    cHi[ax] = fmaxf(cHi[ax], sum[h][ax]);
+                }
+            }
         }
-    }
-    const f3 ce = cHi - cLo;
-    const int axis = ce.x >= ce.y ? (ce.x >= ce.z ? 0 : 2) : (ce.y >= ce.z ? 1 : 2);
-    float key[SPLIT_MAX];
-    uint8_t order[SPLIT_MAX];
-    for (uint32_t i = 0; i < n && i < SPLIT_MAX; ++i) { // insertion sort, stable; NaN keys stay where they are met
-        const float k = corner(i, 0)[axis] + corner(i, 1)[axis] + corner(i, 2)[axis];
-        uint32_t at = i;
-        while (at > 0 && key[at - 1] > k) {
-            key[at] = key[at - 1];
-            order[at] = order[at - 1];
-            --at;
+        for (int o = 32; o > 0; o >>= 1)
+            for (int ax = 0; ax < 3; ++ax) {
+                cLo[ax] = fminf(cLo[ax], __shfl_xor(cLo[ax], o, 64));
+                cHi[ax] = fmaxf(cHi[ax], __shfl_xor(cHi[ax], o, 64));
+            }
+        const f3 ce = cHi - cLo;
+        const int axis = ce.x >= ce.y ? (ce.x >= ce.z ? 0 : 2) : (ce.y >= ce.z ? 1 : 2);
+        // keys as unsigned words that order like the floats (-0 as +0; NaN beyond every number)
+        uint32_t myKey[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const uint32_t i = lane + 64u * h;
+            const uint32_t bits = __float_as_uint(sum[h][axis] + 0.f);
+            myKey[h] = (bits & 0x80000000u) ? ~bits : (bits | 0x80000000u);
+            if (sum[h][axis] != sum[h][axis])
+                myKey[h] = 0xFFFFFFFFu;
+            if (i < n)
+                keys[i] = myKey[h];
         }
-        key[at] = k;
-        order[at] = static_cast<uint8_t>(i);
-    }
-    const int cN = n < 8u ? static_cast<int>(n) : 8;
-    const uint32_t each = n / cN, more = n % cN;
-    uint32_t chunkAt[9];
-    chunkAt[0] = 0;
-    for (int j = 0; j < cN; ++j) {
-        chunkAt[j + 1] = chunkAt[j] + each + (static_cast<uint32_t>(j) < more ? 1u : 0u);
-        AABB b = AABB::Initial();
-        for (uint32_t i = chunkAt[j]; i < chunkAt[j + 1]; ++i)
-            for (int c = 0; c < 3; ++c)
-                b.Expand(corner(order[i], c));
-        b.minPos = b.minPos - pad;
-        b.maxPos = b.maxPos + pad;
-        s_q.set(j, tid, quantise_box(b, fr));
-    }
-    const uint32_t childOf = assign_slots(cN, fr, s_q, tid);
-    Wide8 rec;
-    for (int a = 0; a < 3; ++a) {
-        rec.origin[a] = fr.org[a];
-        rec.exp[a] = static_cast<int8_t>(fr.ex[a]);
-    }
-    rec.imask = 0;
-    rec.childBase = 0;
-    rec.triBase = triBase;
-    uint32_t counts = 0, leafMask = 0, run = 0;
-    for (int sl = 0; sl < 8; ++sl) {
-        rec.off16[sl] = rec.cnt16[sl] = 0;
-        const uint32_t j = (childOf >> (4 * sl)) & 0xFu;
-        if (j == 0xFu) {
-            set_slot_empty(rec, sl);
-            continue;
+        wave_sync();
+        // place of triangle i = keys smaller than its own + equal keys in front of it
+        uint32_t place[2] = {0u, 0u};
+        for (uint32_t j = 0; j < n; ++j) {
+            const uint32_t kj = keys[j];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const uint32_t i = lane + 64u * h;
+                place[h] += (kj < myKey[h] || (kj == myKey[h] && j < i)) ? 1u : 0u;
+            }
         }
-        set_slot_box(rec, sl, s_q.get(j, tid));
-        const uint32_t len = chunkAt[j + 1] - chunkAt[j]; // <= 15
-        for (uint32_t i = chunkAt[j]; i < chunkAt[j + 1]; ++i)
-            args.recSrc[triBase + run + (i - chunkAt[j])] = make_uint2(k0 + order[i], parent);
-        leafMask |= 1u << sl;
-        counts |= len << (4 * sl);
-        rec.off16[sl] = static_cast<uint16_t>(run);
-        rec.cnt16[sl] = static_cast<uint16_t>(len);
-        run += len;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            if (lane + 64u * h < n)
+                order[place[h]] = lane + 64u * h;
+        wave_sync();
+        const uint32_t cN = n < 8u ? n : 8u;
+        const uint32_t each = n / cN, more = n % cN;
+        auto chunk_at = [&](uint32_t j) { return j * each + (j < more ? j : more); };
+        if (static_cast<uint32_t>(lane) < cN) { // the box of chunk `lane`, folded in the order of its triangles
+            AABB b = AABB::Initial();
+            for (uint32_t p = chunk_at(lane); p < chunk_at(lane + 1); ++p) {
+                const uint32_t i = order[p];
+                for (int c = 0; c < 3; ++c)
+                    b.Expand(F3(corner[3 * c][i], corner[3 * c + 1][i], corner[3 * c + 2][i]));
+            }
+            b.minPos = b.minPos - pad;
+            b.maxPos = b.maxPos + pad;
+            s_q.set(lane, col, quantise_box(b, fr));
+        }
+        wave_sync();
+        if (lane == 0) {
+            const uint32_t childOf = assign_slots(static_cast<int>(cN), fr, s_q, col);
+            Wide8 rec;
+            for (int a = 0; a < 3; ++a) {
+                rec.origin[a] = fr.org[a];
+                rec.exp[a] = static_cast<int8_t>(fr.ex[a]);
+            }
+            rec.imask = 0;
+            rec.childBase = 0;
+            rec.triBase = triBase;
+            uint32_t counts = 0, leafMask = 0, run = 0;
+            for (int sl = 0; sl < 8; ++sl) {
+                rec.off16[sl] = rec.cnt16[sl] = 0;
+                const uint32_t j = (childOf >> (4 * sl)) & 0xFu;
+                if (j == 0xFu) {
+                    set_slot_empty(rec, sl);
+                    continue;
+                }
+                set_slot_box(rec, sl, s_q.get(j, col));
+                const uint32_t len = chunk_at(j + 1) - chunk_at(j); // <= 15
+                chunkOut[j] = run;
+                leafMask |= 1u << sl;
+                counts |= len << (4 * sl);
+                rec.off16[sl] = static_cast<uint16_t>(run);
+                rec.cnt16[sl] = static_cast<uint16_t>(len);
+                run += len;
+            }
+            rec.leafMask = leafMask;
+            rec.counts = counts;
+            for (int i = 0; i < 4; ++i)
+                rec.spare[i] = 0;
+            store_record(args.out + w, rec);
+        }
+        wave_sync();
+        // the records' sources, chunk after chunk in slot order
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const uint32_t i = lane + 64u * h;
+            if (i < n) {
+                const uint32_t p = place[h];
+                const uint32_t big = more * (each + 1u); // places in the chunks that are one longer
+                const uint32_t j = p < big ? p / (each + 1u) : more + (p - big) / each;
+                args.recSrc[triBase + chunkOut[j] + (p - chunk_at(j))] = make_uint2(k0 + i, parent);
+            }
+        }
+        wave_sync(); // the wave's LDS rows are written again for its next run node
     }
-    rec.leafMask = leafMask;
-    rec.counts = counts;
-    for (int i = 0; i < 4; ++i)
-        rec.spare[i] = 0;
-    store_record(args.out + w, rec);
 }
 
 __global__ __launch_bounds__(BT) __attribute__((amdgpu_waves_per_eu(4))) void collapse_level_kernel(CollapseArgs args, int level) {
@@ -1074,11 +1146,14 @@ extern "C" int kk_trace_accel_build_with_leaf_boxes(const kk_lbvh_device_data *d
         leafBoxes = own;
     }
     const CollapseArgs args{d_lbvh, d_positions, d_face_pos_idx, leafBoxes, wide, recSrc, rootOf,
-                            reinterpret_cast<uint32_t *>(b + l.leafParent), ctl};
+                            reinterpret_cast<uint32_t *>(b + l.leafParent), ctl,
+                            reinterpret_cast<uint32_t *>(b + l.runList)};
     uint32_t grid = div_up(l.wideMax, BT);
     if (grid > 2048)
         grid = 2048;
-    constexpr int TAIL_FROM = 12; // a launch per level up to here, one workgroup for the rest
+    // a launch per level up to here, one workgroup for the rest; a small tree is one workgroup's work
+    // from the root on (two launches per level would cost more than its levels take)
+    const int TAIL_FROM = nodeNum <= 4096u ? 0 : 12;
     for (int level = 0; level < TAIL_FROM; ++level) {
         // level l has at most 8^l nodes
         const uint32_t g = level < 7 ? (grid < div_up(1u << (3 * level), BT) ? grid : div_up(1u << (3 * level), BT)) : grid;
@@ -1090,7 +1165,7 @@ extern "C" int kk_trace_accel_build_with_leaf_boxes(const kk_lbvh_device_data *d
     collapse_tail_kernel<<<1, BT, 0, stream>>>(args, hdr, TAIL_FROM);
     KK_LAUNCH_CHECK();
     if (face_num - compacted_face_num >= SPLIT_MIN - 1) { // else no leaf is long enough for a run node
-        run_nodes_kernel<<<div_up(l.wideMax, BT), BT, 0, stream>>>(args, hdr);
+        run_nodes_kernel<<<RUN_GRID, BT, 0, stream>>>(args);
         KK_LAUNCH_CHECK();
     }
     fill_records_kernel<<<div_up(face_num, THREADS), THREADS, 0, stream>>>(
