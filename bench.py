@@ -172,6 +172,9 @@ def main():
             with torch.cuda.stream(streams[i & 1]):
                 closest_hit(bvh, rays, out=outs[i & 1])
         torch.cuda.synchronize()
+        # two ray sorts may now run side by side: their tiles take tickets instead of leaning on the
+        # start order of workgroups (kk_sort_set_ticketed)
+        _lib.lib().kk_sort_set_ticketed(1)
         for i in range(4):
             step2(i)
         torch.cuda.synchronize()
@@ -180,7 +183,9 @@ def main():
             step2(i)
         torch.cuda.synchronize()
         ms2 = (time.perf_counter() - t2) * 1e3 / K
+        _lib.lib().kk_sort_set_ticketed(0)
         in_flight = {"Mrays_per_s": round(R / (ms2 * 1e-3) / 1e6, 2), "ms_per_step": round(ms2, 4),
+                     "sort_tiles": "ticketed",
                      "results_equal_one_at_a_time": bool(torch.equal(outs[0][0], outs[1][0]) and
                                                          torch.equal(outs[0][2], outs[1][2]))}
     # the optional watertight triangle test, same rays: throughput and how often its primitive differs
@@ -199,8 +204,36 @@ def main():
                   "prim_mismatch_frac_vs_default": float(wt_mism.float().mean()),
                   "frac_same_prim_with_rel_t_err_above_1e-5": float((wt_rel > 1e-5).float().mean()),
                   "max_rel_t_err_same_prim": float(wt_rel.max()) if wt_rel.numel() else 0.0}
+    # the entry-bound option (groups of pending slots dropped unvisited behind the best hit): same hits,
+    # fewer record visits, more instructions per visit
+    bary_ref = bary.clone()
+    _, _, _, eb_counters = closest_hit(bvh, rays, count=True, entry_bound=True)
+    closest_hit(bvh, rays, out=l_out, entry_bound=True)
+    torch.cuda.synchronize()
+    ev0.record()
+    for _ in range(K):
+        closest_hit(bvh, rays, out=l_out, entry_bound=True)
+    ev1.record()
+    torch.cuda.synchronize()
+    eb_ms = ev0.elapsed_time(ev1) / K
+    eb_equal = bool(torch.equal(prim, prim_ref) and torch.equal(t, t_ref) and torch.equal(bary, bary_ref))
+    ev0.record()
+    for _ in range(K):
+        closest_hit(bvh, rays, out=l_out, entry_bound=True, reuse_order=True)
+    ev1.record()
+    torch.cuda.synchronize()
+    entry_bound = {"Mrays_per_s": round(R / (eb_ms * 1e-3) / 1e6, 2),
+                   "kernel_ms": round(ev0.elapsed_time(ev1) / K, 4),
+                   "node_records_per_ray": round(eb_counters["node_fetches"] / R, 2),
+                   "empty_visits_per_ray": round(eb_counters["empty_visits"] / R, 2),
+                   "empty_visits_by_limit_per_ray": round(eb_counters["empty_visits_by_limit"] / R, 2),
+                   "slots_dropped_unvisited_per_ray": round(eb_counters["slots_dropped_unvisited"] / R, 2),
+                   "results_equal_default": eb_equal}
     closest_hit(bvh, rays, out=l_out)  # leave the default results in the output buffers
     torch.cuda.synchronize()
+    # no step's ray sort gave up (the kernel would have traced in input order, at another rate)
+    from raytracer_amd.ray_tracer import closest_hit_status
+    closest_hit_status(ws, R)
 
     dvr = dvr_head = None
     if not args.no_dvr:
@@ -224,23 +257,40 @@ def main():
     # record tested + 4 B order index + 24 B ray in + 16 B hit out, from the kernel's own work counters
     alg_bytes = 80 * counters["node_fetches"] + 48 * counters["tri_tests"] + (4 + 24 + 16) * R
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+    # the same counters priced as a walk over the reference's 32-byte nodes would be: 32 B per node
+    # visited + 48 B per triangle tested + 24 B ray in + 16 B hit out
+    survey_bytes = 32 * counters["node_fetches"] + 48 * counters["tri_tests"] + (24 + 16) * R
     passes = max(counters["wave_passes"], 1)
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
                 "kernel": "closest_hit_accel_kernel", "avg_launch_ms": round(kernel_ms, 4),
                 "algorithmic_bytes_per_launch": int(alg_bytes),
+                "frac_survey_formula": round(survey_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                "survey_formula": "32 B x node records + 48 B x triangles + 40 B per ray",
+                # HBM is the roofline the fraction is taken against; what the counters of the committed
+                # profile show the kernel waiting for is the CUs' own vector-memory path and VALU issue
+                "limited_by": "CU vector-memory path (per-lane record fetches) and VALU issue, not HBM: see "
+                              "td_busy_frac / valu_busy in the profile digest",
                 "node_records_per_ray": round(counters["node_fetches"] / R, 2),
                 "tri_tests_per_ray": round(counters["tri_tests"] / R, 2),
                 "empty_visits_per_ray": round(counters["empty_visits"] / R, 2),
+                "empty_visits_by_limit_per_ray": round(counters["empty_visits_by_limit"] / R, 2),
                 "lanes_visiting_per_wave_pass": round(counters["visit_lanes"] / passes, 1),
                 "lanes_per_triangle_phase": round(counters["tri_lanes"] / max(counters["tri_phases"], 1), 1)}
     # HBM traffic needs hardware counters (a rocprofv3 --pmc pass), which a plain run cannot read: the
     # figure of the committed counter digest of the same kernel and workload is quoted beside a null
-    for name in ("r02_closest_hit_pmc.json", "r01_closest_hit_pmc.json"):
+    for name in ("r03_closest_hit_pmc.json", "r02_closest_hit_pmc.json", "r01_closest_hit_pmc.json"):
         pmc = os.path.join(ROOT, "profiles", name)
         if os.path.exists(pmc):
             try:
-                roofline["traffic_from_profile"] = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                digest = json.load(open(pmc))
+                roofline["traffic_from_profile"] = digest.get("hbm_bytes_per_launch")
+                if "valu_instructions_per_launch" in digest:
+                    # VALU issue: 4 cycles per wave instruction on 1,024 SIMDs at 2.4 GHz
+                    roofline["valu_issue_floor_ms_from_profile"] = round(
+                        4 * digest["valu_instructions_per_launch"] / (1024 * 2.4e9) * 1e3, 4)
+                    roofline["td_busy_frac_from_profile"] = round(
+                        digest.get("texture_path", {}).get("td_busy_frac", 0.0), 3)
                 roofline["traffic_source"] = (f"profiles/{name}: rocprofv3 --pmc passes of scripts/prof_small.py "
                                               "(same kernel, same workload), not measured in this run")
             except (OSError, ValueError):
@@ -258,6 +308,7 @@ def main():
         "hit_fraction": round(float((prim >= 0).float().mean()), 4),
         "two_batches_in_flight": in_flight,
         "watertight_option": watertight,
+        "entry_bound_option": entry_bound,
     }
     if build_ms is not None:
         gbps = LBVH_BYTES_PER_TRI * N / (build_ms * 1e-3) / 1e9

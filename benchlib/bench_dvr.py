@@ -162,6 +162,8 @@ def run(dev: str, world: int, rank: int, dist=None, frames: int = 720, warmup: i
         from benchlib import two_streams
         from raytracer_amd.multi_gpu import StripeGatherer
         streams = two_streams(dev)
+        from raytracer_amd import _lib as _lib2
+        _lib2.lib().kk_sort_set_ticketed(1)  # tile-order sorts of the two streams may run side by side
         casters2 = [make_caster(), make_caster()]
         for rc in casters2:
             rc.SetAdaptiveTileOrder(True)
@@ -244,6 +246,9 @@ def run(dev: str, world: int, rank: int, dist=None, frames: int = 720, warmup: i
                 casters[i & 1].RenderDepthBoxVDB(fbs[i & 1])
 
         last = warmup + frames - 1
+        # (tile-order sorts of the two streams may run side by side: ticketed tiles, kk_sort_set_ticketed)
+        from raytracer_amd import _lib
+        _lib.lib().kk_sort_set_ticketed(1)
         for key, adaptive in (("fps_two_frames_in_flight_launch_order", False), ("fps_two_frames_in_flight", True)):
             for rc in casters:
                 rc.SetAdaptiveTileOrder(adaptive)
@@ -258,6 +263,10 @@ def run(dev: str, world: int, rank: int, dist=None, frames: int = 720, warmup: i
             out["two_in_flight_last_frame_equals_serial"] = bool(
                 out.get("two_in_flight_last_frame_equals_serial", True) and
                 torch.equal(fbs[last & 1].rgba, fb.rgba))
+        _lib.lib().kk_sort_set_ticketed(0)
+        for rc in casters:
+            rc.CheckTileOrder()
+        caster.CheckTileOrder()
         # work counters of one frame: samples taken and bricks entered
         counters = torch.zeros(2, dtype=torch.int64, device=dev)
         caster.SetCameraToWorld(*poses[warmup])
@@ -274,6 +283,17 @@ def run(dev: str, world: int, rank: int, dist=None, frames: int = 720, warmup: i
                     "compulsory_bytes_per_frame": int(vdb.plan.atlas_voxels) + 4 * W * H,
                     "compulsory_frac_of_hbm_peak": round(
                         (int(vdb.plan.atlas_voxels) + 4 * W * H) / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5)})
+        # the marcher is bound by instruction issue, not by HBM (compulsory_frac_of_hbm_peak above): its
+        # frame against the time its wave instructions need on all SIMDs
+        from benchlib.roofline import valu_issue
+        tag = "dvr_head" if head else "dvr"
+        rl = valu_issue([f"r03_{tag}_pmc.json"] + ([] if head else ["r02_dvr_pmc.json"]), kernel_ms)
+        if rl:
+            rl["kernel"] = "dvr_kernel"
+            rl["frac_two_frames_in_flight"] = round(rl["peak"] / (1e3 / out["fps_two_frames_in_flight"]), 4)
+            rl["frac_launch_order"] = round(rl["peak"] / (1e3 / out["fps_launch_order"]), 4)
+            rl["hbm_frac_of_peak"] = out["compulsory_frac_of_hbm_peak"]
+            out["roofline"] = rl
         if with_cpu:
             from oracle import kkoracle as ko
             cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or (os.cpu_count() or 1)

@@ -67,6 +67,17 @@ def run(dev: str, size=(1920, 1080), spp: int = 16, frames: int = 5, with_cpu: b
            "ms_per_frame_one_call": round(ms_batched, 3),
            "trace_accel_build_ms": round(accel_ms, 4),
            "Mpaths_per_s": round(W * H * spp / (ms * 1e-3) / 1e6, 1)}
+    # the path-tracing kernel is bound by instruction issue and the CUs' memory path, not by HBM: the frame
+    # against the time its wave instructions need on all SIMDs (one dispatch of the profiled kernel is one
+    # sample pass of the 1920 x 1080 frame)
+    if (W, H) == (1920, 1080):
+        from benchlib.roofline import valu_issue
+        rl = valu_issue(["r03_pt_pmc.json", "r02_pt_pmc.json"], ms, dispatches_per_unit=spp,
+                        kernel_contains="<false, 3>")
+        if rl:
+            rl["kernel"] = "path_trace_persistent_kernel<false, 3>"
+            rl["frac_one_call"] = round(rl["peak"] / ms_batched, 4)
+            out["roofline"] = rl
     if with_cpu:
         from oracle import kkoracle as ko
         cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or (os.cpu_count() or 1)

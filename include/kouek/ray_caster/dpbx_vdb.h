@@ -103,10 +103,22 @@ class DepthBoxVDB : Noncopyable {
             kk_memcpy_h2d(deviceDat.atlas_brick_to_node_indices, amap.data(), 4 * amap.size(), nullptr) != KK_OK)
             return fail();
         kk_stream_synchronize(nullptr);
+        // the reference's statistics (src/ray_caster/dpbx_vdb.cu:586-607): sizes of the pools, the atlas in
+        // voxels as the reference's 3-D array would hold it (atlasBrickPerVDB bricks per axis), and the
+        // memory in use - here the atlas holds the valid bricks only, one after the other
+        const auto &pm = plan.param;
+        const size_t atlasBytes = static_cast<size_t>(plan.atlas_voxels) * sizeof(T);
+        const size_t memUsed = plan.node_num * sizeof(Node) + plan.child_num * sizeof(RelativeIndexTy) +
+                               plan.atlas_map_num * sizeof(RelativeIndexTy) + atlasBytes;
         std::cout << "Build VDB with\n\tNode pools of size " << plan.node_num << "x" << sizeof(Node)
-                  << "\n\tChild pools of size " << plan.child_num << "x4\n\tMaps from atlas brick to node index of size "
-                  << plan.atlas_map_num << "x4\n\tAtlas of " << plan.leaf_num << " bricks of "
-                  << plan.param.vox_per_atlas_brick << "^3x" << sizeof(T) << "\n";
+                  << "\n\tChild pools of size " << plan.child_num << "x" << sizeof(RelativeIndexTy)
+                  << "\n\tMaps from atlas brick to node index of size " << plan.atlas_map_num << "x"
+                  << sizeof(RelativeIndexTy) << "\n\tAtlas of size "
+                  << pm.atlas_brick_per_vdb[0] * pm.vox_per_atlas_brick << "x"
+                  << pm.atlas_brick_per_vdb[1] * pm.vox_per_atlas_brick << "x"
+                  << pm.atlas_brick_per_vdb[2] * pm.vox_per_atlas_brick << "x" << sizeof(T) << " (" << plan.leaf_num
+                  << " bricks of " << pm.vox_per_atlas_brick << "^3 stored)\n\tTotal use of memory " << memUsed
+                  << "\n";
         isComplete = true;
     }
 

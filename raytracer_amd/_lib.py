@@ -88,6 +88,7 @@ KK_TRAVERSE_ORDERED = 0
 KK_TRACE_UNSORTED = 1
 KK_TRACE_REUSE_ORDER = 2
 KK_TRACE_WATERTIGHT = 4
+KK_TRACE_ENTRY_BOUND = 8
 
 _lib = None
 

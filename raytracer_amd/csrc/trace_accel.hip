@@ -41,6 +41,8 @@
 
 #include "radix_hist.h"
 
+#include <type_traits>
+
 namespace kk {
 extern "C" size_t kk_sort_workspace_bytes(uint32_t n);
 extern "C" size_t kk_sort_workspace_error_offset(uint32_t n);
@@ -767,6 +769,7 @@ __global__ __launch_bounds__(THREADS) void ray_keys_kernel(const Header *__restr
 
 constexpr int STACK_DEPTH = 48; // <= 1 push per visited record, <= MAX_LEVELS records deep
 constexpr int LDS_DEPTH = 20;   // entries kept in LDS; deeper ones (rare) live in the workspace
+constexpr int LDS_DEPTH_BOUND = 15; // ... when an entry carries its entry bound (8 bytes instead of 6)
 constexpr int REFILL_BELOW = 32;
 constexpr int PARK_MIN = 16; // run the triangle code once this many lanes wait for it ...
 constexpr int STEP_MIN = 24; // ... or fewer than this many lanes can still step
@@ -792,7 +795,15 @@ __device__ __forceinline__ uint32_t xcc_id() { return __builtin_amdgcn_s_getreg(
 // Taking a better triangle hit without checking its parent box first is safe: the limit that prunes
 // the walk is never below the final t, so nothing closer is skipped; if the final hit itself fails
 // the check, the lane walks the ray again with every hit checked as it is taken.
-template <bool COUNT, bool WATERTIGHT>
+//
+// BOUND (KK_TRACE_ENTRY_BOUND): a group also carries a lower bound of the entry distance of its pending
+// slots - the smallest entry among the hit subtree slots of its visit other than the one entered first,
+// 16 bits (the float's upper half, i.e. rounded down) in the stack entry - and what is left of a group is
+// dropped without a visit once that bound lies behind the best hit. Same hits (a slot dropped this way
+// would have been dropped by its record's visit had the limit been known then). On the 10 M-triangle
+// soup it saves 4.05 of 29.7 visits per ray and costs as many instructions per visit as it saves
+// visits: 1.225 ms against 1.178 ms per launch, so it is an option, not the default.
+template <bool COUNT, bool WATERTIGHT, bool BOUND>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(5, 5))) void closest_hit_accel_kernel(
     const Header *__restrict__ hdr, const Wide8 *__restrict__ wide, const TriRec *__restrict__ recs,
     const float *__restrict__ rays, const uint32_t *__restrict__ order, uint32_t rayNum,
@@ -800,12 +811,15 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(5, 5)))
     uint32_t *rayCounter, const uint32_t *__restrict__ parents,
     uint2 *__restrict__ spill, unsigned long long *counters, const uint32_t *sortError, uint32_t *status) {
     // groups waiting to be entered: childBase + (pending slots | internal-slot mask << 8)
+    // (BOUND: the second word is 32 bits, its upper half the entry bound)
+    constexpr int LDS_DEPTH = BOUND ? LDS_DEPTH_BOUND : accel::LDS_DEPTH;
+    using BitsWord = typename std::conditional<BOUND, uint32_t, unsigned short>::type;
     __shared__ uint32_t s_base[LDS_DEPTH * THREADS];
-    __shared__ unsigned short s_bits[LDS_DEPTH * THREADS];
+    __shared__ BitsWord s_bits[LDS_DEPTH * THREADS];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     uint32_t *stBase = s_base + tid;
-    unsigned short *stBits = s_bits + tid;
+    BitsWord *stBits = s_bits + tid;
     const size_t spillStride = static_cast<size_t>(gridDim.x) * THREADS;
     uint2 *mySpill = spill + static_cast<size_t>(blockIdx.x) * THREADS + tid;
     // A ray sort whose look-back gave up leaves an order that is no permutation of the rays: the rays are
@@ -838,14 +852,17 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(5, 5)))
     Shear shear{};                                 // WATERTIGHT: the ray's shear, made once per ray
     uint32_t cur = 0;                              // node to visit next
     bool have = false;                             // cur is valid
-    uint32_t grpBase = 0, grpBits = 0;             // current group (see above)
+    float grpMin = 0.f;                            // lower bound of the entry distance of the group's pending slots,
+    constexpr uint32_t FRESH = BOUND ? 0x10000u : 0u; // which does not cover the group's first slot while that is pending
+                                                   // (bit 16 of grpBits, in the registers only)
+    uint32_t grpBase = 0, grpBits = 0;             // current group (see above); bits 16-31: entry bound
     uint32_t mode = MODE_FAST;                     // how hits of this ray are checked (see test_run)
     int sp = 0;
     uint32_t pendW = 0, pendC = 0; // parked triangles
     Hit8 best;
     uint32_t nodeVisits = 0, triTests = 0;
     unsigned long long totNodes = 0, totTris = 0, totRays = 0;
-    unsigned long long dbgIters = 0, dbgVisitLanes = 0, dbgTriRuns = 0, dbgTriLanes = 0, dbgEmpty = 0, dbgEmptyLimit = 0, dbgUsedSlots = 0, dbgLeafOnly = 0;
+    unsigned long long dbgIters = 0, dbgVisitLanes = 0, dbgTriRuns = 0, dbgTriLanes = 0, dbgEmpty = 0, dbgEmptyLimit = 0, dbgUsedSlots = 0, dbgLeafOnly = 0, dbgCulled = 0;
 
     auto restart = [&]() {
         best.t = FloatMax;
@@ -856,7 +873,8 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(5, 5)))
         pendC = 0u;
         // a group that holds just the root: slot 0 of a node whose only internal slot is slot 0
         grpBase = 0u;
-        grpBits = (1u << (0u ^ sg.oct)) | (1u << 8);
+        grpBits = (1u << (0u ^ sg.oct)) | (1u << 8) | FRESH;
+        grpMin = 0.f;
         have = false;
         active = true;
     };
@@ -920,13 +938,14 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(5, 5)))
                         // same for the whole wave and the record comes through the scalar cache instead
                         // of five per-lane loads.
                         bool anyNoLimit = false;
-                        const Visit vis = visit_record<false>(wideBytes, 0u, ray, sg, FloatMax, anyNoLimit);
+                        const Visit vis = visit_record<false, BOUND>(wideBytes, 0u, ray, sg, FloatMax, anyNoLimit);
                         if (COUNT)
                             ++nodeVisits;
                         pendW = vis.leafW;
                         pendC = vis.leafC;
                         grpBase = vis.childBase;
-                        grpBits = octant_order(vis.inner, sg.oct) | (vis.imask << 8);
+                        grpBits = octant_order(vis.inner, sg.oct) | (vis.imask << 8) | FRESH;
+                        grpMin = vis.restEntry;
                         if ((vis.inner | vis.leafC) == 0u) { // nothing of the root is hit
                             active = false;
                             finished = true;
@@ -945,25 +964,38 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(5, 5)))
             const float limit = best.t + trav::CULL_SLACK * best.t;
             // ---- (A) next node: from the current group, else from the stack ------------------------
             if (active && !have && pendC == 0u) {
-                if ((grpBits & 0xffu) == 0u) {
-                    if (sp > 0) {
-                        --sp;
-                        if (sp < LDS_DEPTH) {
-                            grpBase = stBase[sp * THREADS];
-                            grpBits = stBits[sp * THREADS];
-                        } else if (sp < STACK_DEPTH) {
-                            const uint2 e = mySpill[(sp - LDS_DEPTH) * spillStride];
-                            grpBase = e.x;
-                            grpBits = e.y;
-                        }
-                    } else { // walk over
-                        active = false;
-                        finished = true;
+                // what is left of the group lies behind the best hit by now: dropped unvisited
+                if (BOUND && !(grpBits & FRESH) && grpMin * SLAB_SHRINK > limit) {
+                    if (COUNT)
+                        dbgCulled += __popc(grpBits & 0xffu);
+                    grpBits &= ~0xffu;
+                }
+                while ((grpBits & 0xffu) == 0u && sp > 0) {
+                    --sp;
+                    if (sp < LDS_DEPTH) {
+                        grpBase = stBase[sp * THREADS];
+                        grpBits = stBits[sp * THREADS];
+                    } else if (sp < STACK_DEPTH) {
+                        const uint2 e = mySpill[(sp - LDS_DEPTH) * spillStride];
+                        grpBase = e.x;
+                        grpBits = e.y;
+                    }
+                    if (!BOUND)
+                        break; // one group per pass
+                    grpMin = __uint_as_float(grpBits & 0xFFFF0000u);
+                    grpBits &= 0xFFFFu;
+                    if (grpMin * SLAB_SHRINK > limit) {
+                        if (COUNT)
+                            dbgCulled += __popc(grpBits & 0xffu);
+                        grpBits &= ~0xffu;
                     }
                 }
-                if ((grpBits & 0xffu) != 0u) {
+                if ((grpBits & 0xffu) == 0u) { // walk over
+                    active = false;
+                    finished = true;
+                } else {
                     const uint32_t i = static_cast<uint32_t>(__ffs(static_cast<int>(grpBits))) - 1u;
-                    grpBits &= grpBits - 1u; // the lowest set bit is a pending slot
+                    grpBits &= (grpBits - 1u) & (BOUND ? 0xFFFFu : ~0u); // the lowest set bit is a pending slot
                     const uint32_t slot = i ^ sg.oct;
                     cur = grpBase + __popc((grpBits >> 8) & ((1u << slot) - 1u));
                     have = true;
@@ -979,7 +1011,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(5, 5)))
                 if (COUNT)
                     ++nodeVisits;
                 bool anyNoLimit = false;
-                const Visit vis = visit_record<COUNT>(wideBytes, cur, ray, sg, limit, anyNoLimit);
+                const Visit vis = visit_record<COUNT, BOUND>(wideBytes, cur, ray, sg, limit, anyNoLimit);
                 if (COUNT) {
                     dbgUsedSlots += __popc(vis.imask | vis.leafSlots);
                     if (vis.imask == 0u)
@@ -996,15 +1028,17 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(5, 5)))
                 }
                 if (vis.inner != 0u) {
                     if ((grpBits & 0xffu) != 0u) {
+                        const uint32_t word = (grpBits & 0xFFFFu) | (BOUND ? __float_as_uint(grpMin) & 0xFFFF0000u : 0u);
                         if (sp < LDS_DEPTH) {
                             stBase[sp * THREADS] = grpBase;
-                            stBits[sp * THREADS] = static_cast<unsigned short>(grpBits);
+                            stBits[sp * THREADS] = static_cast<BitsWord>(word);
                         } else if (sp < STACK_DEPTH)
-                            mySpill[(sp - LDS_DEPTH) * spillStride] = make_uint2(grpBase, grpBits);
+                            mySpill[(sp - LDS_DEPTH) * spillStride] = make_uint2(grpBase, word);
                         ++sp;
                     }
                     grpBase = vis.childBase;
-                    grpBits = octant_order(vis.inner, sg.oct) | (vis.imask << 8);
+                    grpBits = octant_order(vis.inner, sg.oct) | (vis.imask << 8) | FRESH;
+                    grpMin = vis.restEntry;
                 }
             }
             // ---- (C) triangle phase, when it pays --------------------------------------------------
@@ -1049,12 +1083,14 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(5, 5)))
             dbgEmptyLimit += __shfl_xor(dbgEmptyLimit, o, 64);
             dbgUsedSlots += __shfl_xor(dbgUsedSlots, o, 64);
             dbgLeafOnly += __shfl_xor(dbgLeafOnly, o, 64);
+            dbgCulled += __shfl_xor(dbgCulled, o, 64);
         }
         if (lane == 0) {
             atomicAdd(&counters[7], dbgEmpty);
             atomicAdd(&counters[8], dbgEmptyLimit);
             atomicAdd(&counters[9], dbgUsedSlots);
             atomicAdd(&counters[10], dbgLeafOnly);
+            atomicAdd(&counters[11], dbgCulled);
         }
     }
 }
@@ -1066,7 +1102,7 @@ inline TraceWs trace_ws(uint32_t rayNum) {
     TraceWs w;
     Carver c;
     const size_t n = rayNum ? rayNum : 1;
-    w.spill = c.take(sizeof(uint2) * MAX_GRID * THREADS * (STACK_DEPTH - LDS_DEPTH));
+    w.spill = c.take(sizeof(uint2) * MAX_GRID * THREADS * (STACK_DEPTH - LDS_DEPTH_BOUND));
     w.keysA = c.take(4 * n);
     w.keysB = c.take(4 * n);
     w.valsA = c.take(4 * n);
@@ -1240,7 +1276,7 @@ extern "C" int kk_closest_hit_accel(const void *d_accel, uint32_t face_num,
     KK_REQUIRE(face_num > 0 && compacted_face_num > 0 && compacted_face_num <= face_num,
                "tree sizes out of range");
     KK_REQUIRE((flags & ~static_cast<uint32_t>(KK_TRACE_UNSORTED | KK_TRACE_REUSE_ORDER |
-                                               KK_TRACE_WATERTIGHT)) == 0,
+                                               KK_TRACE_WATERTIGHT | KK_TRACE_ENTRY_BOUND)) == 0,
                "unknown flag");
     if (ray_num == 0)
         return KK_OK;
@@ -1294,20 +1330,26 @@ extern "C" int kk_closest_hit_accel(const void *d_accel, uint32_t face_num,
     uint2 *spill = reinterpret_cast<uint2 *>(b + w.spill);
     const auto *parents = reinterpret_cast<const uint32_t *>(ab + l.parents);
     const bool wt = (flags & KK_TRACE_WATERTIGHT) != 0;
-#define KK_LAUNCH_TRACE(COUNT, WT)                                                                 \
-    closest_hit_accel_kernel<COUNT, WT><<<grid, THREADS, 0, stream>>>(                              \
+#define KK_LAUNCH_TRACE(COUNT, WT, BOUND)                                                          \
+    closest_hit_accel_kernel<COUNT, WT, BOUND><<<grid, THREADS, 0, stream>>>(                       \
         hdr, wide, recs, d_rays, order, ray_num, d_t, d_bary, d_prim, rayCounter, parents, spill,  \
         d_counters, sortError, status)
+    const bool bound = (flags & KK_TRACE_ENTRY_BOUND) != 0;
+    KK_REQUIRE(!(bound && wt), "KK_TRACE_ENTRY_BOUND and KK_TRACE_WATERTIGHT do not combine");
     if (d_counters) {
         if (wt)
-            KK_LAUNCH_TRACE(true, true);
+            KK_LAUNCH_TRACE(true, true, false);
+        else if (bound)
+            KK_LAUNCH_TRACE(true, false, true);
         else
-            KK_LAUNCH_TRACE(true, false);
+            KK_LAUNCH_TRACE(true, false, false);
     } else {
         if (wt)
-            KK_LAUNCH_TRACE(false, true);
+            KK_LAUNCH_TRACE(false, true, false);
+        else if (bound)
+            KK_LAUNCH_TRACE(false, false, true);
         else
-            KK_LAUNCH_TRACE(false, false);
+            KK_LAUNCH_TRACE(false, false, false);
     }
 #undef KK_LAUNCH_TRACE
     KK_LAUNCH_CHECK();

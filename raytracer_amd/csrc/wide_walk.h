@@ -413,6 +413,14 @@ __device__ __forceinline__ void prepare_ray(f3 pos, f3 dir, RayState &ray, RaySi
     sg.oct = (sg.negX ? 1u : 0u) | (sg.negY ? 2u : 0u) | (sg.negZ ? 4u : 0u);
 }
 
+// bit i of the result = slot i ^ oct of `slots`: ascending bits run front to back for the ray's octant
+__device__ __forceinline__ uint32_t octant_order(uint32_t slots, uint32_t oct) {
+    slots = (oct & 1u) ? (((slots & 0xAAu) >> 1) | ((slots & 0x55u) << 1)) : slots;
+    slots = (oct & 2u) ? (((slots & 0xCCu) >> 2) | ((slots & 0x33u) << 2)) : slots;
+    slots = (oct & 4u) ? (((slots & 0xF0u) >> 4) | ((slots & 0x0Fu) << 4)) : slots;
+    return slots;
+}
+
 // What a visit of one record found.
 struct Visit {
     uint32_t inner;        // hit slots that hold subtrees, bit = slot
@@ -423,12 +431,14 @@ struct Visit {
     uint32_t leafHits;     // the leaf slots that are hit
     uint32_t counts;       // the record's count word (4 bits per slot unless LONG_RUN / HUGE_RUN)
     uint32_t flags;        // the record's leaf word (leafSlots, LONG_RUN, HUGE_RUN)
+    float restEntry;       // REST: smallest entry distance among the hit subtree slots other than the one
+                           // that comes first in the ray's octant order (+inf when there is no other)
 };
 
 // Slab tests of the eight slots of record `cur` against the ray, conservative: a slot is dropped only
 // when it is missed beyond the rounding margin or entered beyond `limit`. DIAG also reports whether
 // any slot would be hit without the limit.
-template <bool DIAG>
+template <bool DIAG, bool REST = false>
 __device__ __forceinline__ Visit visit_record(const char *__restrict__ wideBytes, uint32_t cur,
                                               const RayState &ray, const RaySigns &sg, float limit,
                                               bool &anyNoLimit) {
@@ -454,6 +464,7 @@ __device__ __forceinline__ Visit visit_record(const char *__restrict__ wideBytes
     // A slot is kept unless it is missed beyond the rounding margin: the sign of
     // exit - entry * (1 - margin) is shifted into `missed`, slot 7 first.
     uint32_t missed = 0;
+    float en[8];
 #pragma unroll
     for (int pr = 3; pr >= 0; --pr) {
         const int h = pr >> 1, sh = 16 * (pr & 1); // slots 2 pr and 2 pr + 1
@@ -472,6 +483,8 @@ __device__ __forceinline__ Visit visit_record(const char *__restrict__ wideBytes
         const float en1 = fmaxf(fmaxf(fmaxf(hnx.y, hny.y), hnz.y), 0.f);
         const float en0 = fmaxf(fmaxf(fmaxf(hnx.x, hny.x), hnz.x), 0.f);
         const float far1 = fminf(fminf(hfx.y, hfy.y), hfz.y), far0 = fminf(fminf(hfx.x, hfy.x), hfz.x);
+        en[2 * pr] = en0;
+        en[2 * pr + 1] = en1;
         if (DIAG)
             anyNoLimit |= !(en1 * SLAB_SHRINK > far1) || !(en0 * SLAB_SHRINK > far0);
         const float ex1 = fminf(far1, limit), ex0 = fminf(far0, limit);
@@ -483,6 +496,22 @@ __device__ __forceinline__ Visit visit_record(const char *__restrict__ wideBytes
     v.imask = r0.w >> 24;
     v.childBase = r1.x;
     v.inner = hits & v.imask;
+    v.restEntry = __builtin_inff();
+    if (REST) {
+        // (entry distances are >= +0: their bits order like the values; a slot that is not wanted reads
+        // as all ones)
+        const uint32_t inner = v.inner & 0xffu;
+        const uint32_t firstI = static_cast<uint32_t>(__ffs(static_cast<int>(octant_order(inner, sg.oct)))) - 1u;
+        const uint32_t rest = inner & ~(1u << ((firstI ^ sg.oct) & 7u)); // (inner == 0: nothing to clear)
+        const int unwanted = static_cast<int>(~rest);
+        uint32_t key[8];
+#pragma unroll
+        for (int sl = 0; sl < 8; ++sl) // bit sl of `unwanted` spread over the word: 0 or all ones
+            key[sl] = __float_as_uint(en[sl]) | static_cast<uint32_t>(__builtin_amdgcn_sbfe(unwanted, sl, 1));
+        auto min3 = [](uint32_t a, uint32_t b, uint32_t c) { return min(min(a, b), c); };
+        const uint32_t m = min3(min3(key[0], key[1], key[2]), min3(key[3], key[4], key[5]), min(key[6], key[7]));
+        v.restEntry = m == 0xFFFFFFFFu ? __builtin_inff() : __uint_as_float(m);
+    }
     v.leafSlots = r1.z & 0xffu;
     v.leafW = v.leafC = 0u;
     const uint32_t leafHits = hits & r1.z & 0xffu;
@@ -514,14 +543,6 @@ __device__ __forceinline__ Visit visit_record(const char *__restrict__ wideBytes
         }
     }
     return v;
-}
-
-// bit i of the result = slot i ^ oct of `slots`: ascending bits run front to back for the ray's octant
-__device__ __forceinline__ uint32_t octant_order(uint32_t slots, uint32_t oct) {
-    slots = (oct & 1u) ? (((slots & 0xAAu) >> 1) | ((slots & 0x55u) << 1)) : slots;
-    slots = (oct & 2u) ? (((slots & 0xCCu) >> 2) | ((slots & 0x33u) << 2)) : slots;
-    slots = (oct & 4u) ? (((slots & 0xF0u) >> 4) | ((slots & 0x0Fu) << 4)) : slots;
-    return slots;
 }
 
 // ---- whole-ray walks for kernels that give each lane one ray after another ----------------------------

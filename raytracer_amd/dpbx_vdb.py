@@ -83,11 +83,33 @@ class DepthBoxVDB:
             return
         self._complete = True
         if self.verbose:
-            print("Build VDB with\n"
-                  f"\tNode pools of size {self.GetNodePoolsSize()}x32\n"
-                  f"\tChild pools of size {self.GetChildPoolsSize()}x4\n"
-                  f"\tMaps from atlas brick to node index of size {self.GetAtlasBrickToNodeIndicesSize()}x4\n"
-                  f"\tAtlas of {self.plan.leaf_num} bricks x {self.plan.param.vox_per_atlas_brick}^3 x {self.voxel_bytes}")
+            print(self.statistics_text())
+
+    def memory_statistics(self) -> dict:
+        """What the reference prints after a build (src/ray_caster/dpbx_vdb.cu:586-607): element counts and
+        sizes of the pools, the atlas extent in voxels as the reference's 3-D array holds it, and the bytes
+        in use (here the atlas stores the valid bricks only, one after the other)."""
+        pm = self.plan.param
+        e = int(pm.vox_per_atlas_brick)
+        atlas_bytes = int(self.plan.atlas_voxels) * self.voxel_bytes
+        return {"node_pools": (self.GetNodePoolsSize(), 32), "child_pools": (self.GetChildPoolsSize(), 4),
+                "atlas_brick_to_node_indices": (self.GetAtlasBrickToNodeIndicesSize(), 4),
+                "atlas_size": (int(pm.atlas_brick_per_vdb[0]) * e, int(pm.atlas_brick_per_vdb[1]) * e,
+                               int(pm.atlas_brick_per_vdb[2]) * e, self.voxel_bytes),
+                "atlas_bricks_stored": int(self.plan.leaf_num),
+                "total_bytes": (self.GetNodePoolsSize() * 32 + self.GetChildPoolsSize() * 4 +
+                                self.GetAtlasBrickToNodeIndicesSize() * 4 + atlas_bytes)}
+
+    def statistics_text(self) -> str:
+        m = self.memory_statistics()
+        a = m["atlas_size"]
+        return ("Build VDB with\n"
+                f"\tNode pools of size {m['node_pools'][0]}x{m['node_pools'][1]}\n"
+                f"\tChild pools of size {m['child_pools'][0]}x{m['child_pools'][1]}\n"
+                f"\tMaps from atlas brick to node index of size {m['atlas_brick_to_node_indices'][0]}x4\n"
+                f"\tAtlas of size {a[0]}x{a[1]}x{a[2]}x{a[3]} ({m['atlas_bricks_stored']} bricks of "
+                f"{int(self.plan.param.vox_per_atlas_brick)}^3 stored)\n"
+                f"\tTotal use of memory {m['total_bytes']}")
 
     def IsComplete(self) -> bool:
         return self._complete

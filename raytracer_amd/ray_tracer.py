@@ -22,7 +22,8 @@ def closest_hit_status(workspace, ray_num: int) -> None:
 
 
 def closest_hit(lbvh: LBVH, rays, count: bool = False, out=None, layout: str = "trace", sort: bool = True,
-                reuse_order: bool = False, watertight: bool = False, check: bool = False):
+                reuse_order: bool = False, watertight: bool = False, check: bool = False,
+                entry_bound: bool = False):
     """Traces rays [R,6] (pos, dir) through a built LBVH with rayCastLBVH<false>'s result semantics
     (src/ray_tracer/ray_tracer_render.cu:192-270). Returns torch tensors (t [R], bary [R,2],
     prim [R] int32 with -1 = miss) and, when `count`, a dict of work counters.
@@ -31,7 +32,8 @@ def closest_hit(lbvh: LBVH, rays, count: bool = False, out=None, layout: str = "
     ray order found by the previous call with the same `out` workspace (same rays). watertight swaps the
     triangle test for the watertight one (trace layout only; hits may differ on grazing rays). check
     waits for the call and raises if its ray sort gave up (closest_hit_status; a loop that must not
-    synchronise per call passes its own `out` and asks once at the end)."""
+    synchronise per call passes its own `out` and asks once at the end). entry_bound: groups of pending
+    slots carry a bound of their entry distance and are dropped unvisited behind the best hit (same hits)."""
     l = _lib.lib()
     dev = lbvh.device
     d_rays = rays if isinstance(rays, torch.Tensor) else torch.from_numpy(
@@ -57,7 +59,8 @@ def closest_hit(lbvh: LBVH, rays, count: bool = False, out=None, layout: str = "
                                               bary.data_ptr(), prim.data_ptr(),
                                               (_lib.KK_TRACE_REUSE_ORDER if reuse_order else
                                                (0 if sort else _lib.KK_TRACE_UNSORTED)) |
-                                              (_lib.KK_TRACE_WATERTIGHT if watertight else 0),
+                                              (_lib.KK_TRACE_WATERTIGHT if watertight else 0) |
+                                              (_lib.KK_TRACE_ENTRY_BOUND if entry_bound else 0),
                                               counters.data_ptr() if count else None, ws.data_ptr(),
                                               ws.numel(), _lib.current_stream_ptr()),
                        "kk_closest_hit_accel")
@@ -76,7 +79,7 @@ def closest_hit(lbvh: LBVH, rays, count: bool = False, out=None, layout: str = "
                                "wave_passes": int(c[3]), "visit_lanes": int(c[4]), "tri_phases": int(c[5]),
                                "tri_lanes": int(c[6]), "empty_visits": int(c[7]),
                                "empty_visits_by_limit": int(c[8]), "used_slots_visited": int(c[9]),
-                               "leaf_only_visits": int(c[10])}
+                               "leaf_only_visits": int(c[10]), "slots_dropped_unvisited": int(c[11])}
     return t, bary, prim
 
 

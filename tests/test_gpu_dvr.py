@@ -85,6 +85,16 @@ def test_build_head_shape(oracle):
     vdb, ref = _build_both(oracle, vol, (5, 4, 3), HEAD_TF.empty_scalar_ranges)
     _compare_build(vdb, ref)
     assert vdb.plan.param.root_lev == 1 and vdb.plan.param.vox_per_vdb == 512.0
+    # the statistics the reference prints after a build (src/ray_caster/dpbx_vdb.cu:586-607)
+    m = vdb.memory_statistics()
+    assert m["node_pools"] == (len(ref.nodes), 32) and m["child_pools"] == (len(ref.child_pools), 4)
+    assert m["atlas_brick_to_node_indices"] == (len(ref.atlas_brick_to_node), 4)
+    e = int(vdb.plan.param.vox_per_atlas_brick)
+    assert m["atlas_size"][:3] == tuple(int(b) * e for b in ref.param["atlasBrickPerVDB"])
+    assert m["total_bytes"] == (32 * len(ref.nodes) + 4 * len(ref.child_pools) +
+                                4 * m["atlas_brick_to_node_indices"][0] + m["atlas_bricks_stored"] * e ** 3)
+    text = vdb.statistics_text()
+    assert text.startswith("Build VDB with\n\tNode pools of size") and "Total use of memory" in text
 
 
 def test_build_two_ranges(oracle):
