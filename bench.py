@@ -191,6 +191,7 @@ def main():
     # the optional watertight triangle test, same rays: throughput and how often its primitive differs
     prim_ref = prim.clone()
     t_ref = t.clone()
+    bary_ref = bary.clone()
     ev0.record()
     for _ in range(K):
         closest_hit(bvh, rays, out=l_out, watertight=True)
@@ -206,7 +207,6 @@ def main():
                   "max_rel_t_err_same_prim": float(wt_rel.max()) if wt_rel.numel() else 0.0}
     # the entry-bound option (groups of pending slots dropped unvisited behind the best hit): same hits,
     # fewer record visits, more instructions per visit
-    bary_ref = bary.clone()
     _, _, _, eb_counters = closest_hit(bvh, rays, count=True, entry_bound=True)
     closest_hit(bvh, rays, out=l_out, entry_bound=True)
     torch.cuda.synchronize()

@@ -7,6 +7,13 @@ if [ "$what" = all ]; then
   bash scripts/pmc_pass.sh dtex all TA_TA_BUSY_sum TD_TD_BUSY_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum GRBM_GUI_ACTIVE || exit 1
   bash scripts/pmc_pass.sh dsq2 all SQ_INSTS_BRANCH SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SMEM || exit 1
   python3 scripts/pmc_summary.py gpurun_out > gpurun_out/summary_pmc_all.json
+elif [ "$what" = head ]; then
+  # the marcher on the Head-shape volume at 1080p: instruction and memory-path counters only
+  rm -rf gpurun_out/pmc_*
+  bash scripts/pmc_pass.sh head_sq dvr_head SQ_WAVES SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_SALU || exit 1
+  bash scripts/pmc_pass.sh head_tex dvr_head TA_TA_BUSY_sum TD_TD_BUSY_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum GRBM_GUI_ACTIVE || exit 1
+  bash scripts/pmc_pass.sh head_sq2 dvr_head SQ_INSTS_BRANCH SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SMEM || exit 1
+  python3 scripts/pmc_summary.py gpurun_out > gpurun_out/summary_pmc_head.json
 else
   cd /tmp && export TMPDIR=/tmp
   R=$GRAFT_REPO_ROOT

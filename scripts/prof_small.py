@@ -1,5 +1,5 @@
 """Short profiling driver (for rocprofv3 --pmc passes): one LBVH build of the 10 M-triangle soup, three
-closest-hit launches of 2 M rays, and optionally DVR frames of the Kingsnake-shape volume at 4K ("dvr") or path-tracer sample passes of
+closest-hit launches of 2 M rays, and optionally DVR frames of the Kingsnake-shape volume at 4K ("dvr"), of the Head-shape volume at 1080p ("dvr_head") or path-tracer sample passes of
 veach-mis at 1080p ("pt")."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -22,6 +22,10 @@ if what in ("path1", "all"):
 if what in ("dvr", "all"):
     from benchlib import bench_dvr
     print(bench_dvr.run("cuda:0", 1, 0, None, frames=4, warmup=2, with_cpu=False))
+if what in ("dvr_head",):
+    from benchlib import bench_dvr
+    print(bench_dvr.run("cuda:0", 1, 0, None, frames=4, warmup=2, with_cpu=False, workload="head",
+                        dim=(128, 256, 256), size=(1920, 1080)))
 if what in ("pt",):
     from benchlib import bench_pt
     print(bench_pt.run("cuda:0", spp=4, frames=1, with_cpu=False))
