@@ -73,9 +73,9 @@ def run(dev: str, size=(1920, 1080), spp: int = 16, frames: int = 5, with_cpu: b
     if (W, H) == (1920, 1080):
         from benchlib.roofline import valu_issue
         rl = valu_issue(["r03_pt_pmc.json", "r02_pt_pmc.json"], ms, dispatches_per_unit=spp,
-                        kernel_contains="<false, 3>")
+                        kernel_contains="<false, 3,")
         if rl:
-            rl["kernel"] = "path_trace_persistent_kernel<false, 3>"
+            rl["kernel"] = "path_trace_persistent_kernel<false, 3, false>"
             rl["frac_one_call"] = round(rl["peak"] / ms_batched, 4)
             out["roofline"] = rl
     if with_cpu:

@@ -5,7 +5,7 @@ import sys
 
 src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/summary_pmc_all.json"
 d = json.load(open(src))
-name = next(k for k in d if "closest_hit_accel_kernel<false, false>" in k)
+name = next(k for k in d if "closest_hit_accel_kernel<false, false" in k)
 c = d[name]
 reads = c["TCC_EA0_RDREQ_sum"] * 128  # every read request of this kernel is a 128-byte line
 writes = c["WRITE_SIZE"] * 1024
