@@ -196,7 +196,10 @@ __global__ __launch_bounds__(THREADS) void morton_kernel(const float *__restrict
     rsort::hist_clear<4>(s_hist, threadIdx.x, THREADS);
     const f3 minPos = {params->minPos[0], params->minPos[1], params->minPos[2]};
     const f3 invDlt = {params->invDlt[0], params->invDlt[1], params->invDlt[2]};
-    for (uint32_t fi = blockIdx.x * THREADS + threadIdx.x; fi < faceNum; fi += gridDim.x * THREADS) {
+    // From the last face to the first: bounds_partial has just streamed the positions front to back and the
+    // Infinity Cache holds what it read last.
+    for (uint32_t k = blockIdx.x * THREADS + threadIdx.x; k < faceNum; k += gridDim.x * THREADS) {
+        const uint32_t fi = faceNum - 1u - k;
         AABB box = AABB::Initial();
         box.Expand(load3(pos, tri[3ull * fi]));
         box.Expand(load3(pos, tri[3ull * fi + 1]));
@@ -623,9 +626,12 @@ __global__ __launch_bounds__(REFIT_THREADS) void refit_window_kernel(
     __shared__ float2 s_tab[TAB_ENTRIES];        // s_tab[tab_off(k) + j] = fold of leaves [j, j + 2^k)
     __shared__ float2 s_coarse[COARSE_ENTRIES];  // s_coarse[coarse_off(k) + b] = fold of leaves [32 b, 32 b + 2^k)
     const uint32_t M = hdr->compacted_face_num;
-    const uint32_t b0 = blockIdx.x * REFIT_LEAVES;
-    if (b0 >= M)
+    // From the last window to the first: karras_links has just written the leaf boxes and links front to
+    // back and the Infinity Cache holds what it wrote last.
+    const uint32_t windows = (M + REFIT_LEAVES - 1u) / REFIT_LEAVES;
+    if (blockIdx.x >= windows)
         return;
+    const uint32_t b0 = (windows - 1u - blockIdx.x) * REFIT_LEAVES;
     const uint32_t b1 = (b0 + REFIT_LEAVES < M) ? b0 + REFIT_LEAVES : M; // leaves [b0, b1)
     const int tid = threadIdx.x;
     if (M == 1) {
