@@ -286,9 +286,12 @@ def main():
                 digest = json.load(open(pmc))
                 roofline["traffic_from_profile"] = digest.get("hbm_bytes_per_launch")
                 if "valu_instructions_per_launch" in digest:
-                    # VALU issue: 4 cycles per wave instruction on 1,024 SIMDs at 2.4 GHz
+                    # VALU issue: 0.6 G wave instructions per second and SIMD (4 cycles at 2.4 GHz) on 1,024
+                    # SIMDs; a mixed stream was measured at 0.72 (benchlib/roofline.py says how)
                     roofline["valu_issue_floor_ms_from_profile"] = round(
                         4 * digest["valu_instructions_per_launch"] / (1024 * 2.4e9) * 1e3, 4)
+                    roofline["valu_issue_floor_ms_at_measured_mix_rate"] = round(
+                        digest["valu_instructions_per_launch"] / (1024 * 0.72e9) * 1e3, 4)
                     roofline["td_busy_frac_from_profile"] = round(
                         digest.get("texture_path", {}).get("td_busy_frac", 0.0), 3)
                 roofline["traffic_source"] = (f"profiles/{name}: rocprofv3 --pmc passes of scripts/prof_small.py "
