@@ -48,9 +48,10 @@ inline bool scanUInt(const char *&s, uint32_t &v) {
     if (*s < '0' || *s > '9')
         return false;
     char *end = nullptr;
-    v = static_cast<uint32_t>(std::strtoul(s, &end, 10));
+    const unsigned long long x = std::strtoull(s, &end, 10);
     s = end;
-    return true;
+    v = static_cast<uint32_t>(x);
+    return x <= 0xFFFFFFFFull; // (a larger number must not wrap into a valid index)
 }
 inline float dot3(const vec3 &a, const vec3 &b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
 inline vec3 sub3(const vec3 &a, const vec3 &b) { return vec3(a[0] - b[0], a[1] - b[1], a[2] - b[2]); }
@@ -150,6 +151,8 @@ class OBJMesh {
                     if (ok && i % 3 != 2)
                         ok = *s++ == '/';
                 }
+                for (int i = 0; i < 9 && ok; ++i)
+                    ok = v[i] != 0; // indices count from one (the reference lets a zero wrap to 2^32 - 1)
                 if (!ok) {
                     bad();
                     return;
@@ -181,6 +184,10 @@ class OBJMesh {
                     return;
                 break;
             case 6: {
+                if (grpStartFaceIndices.empty()) { // a material belongs to a group (the reference indexes group -1 here)
+                    bad();
+                    return;
+                }
                 if (prevGrpIsLight &&
                     !appendLight(prevGrpLight, static_cast<IndexTy>(grpStartFaceIndices.size()) - 2))
                     return;
@@ -205,6 +212,16 @@ class OBJMesh {
         }
         if (prevGrpIsLight && !appendLight(prevGrpLight, static_cast<IndexTy>(grpStartFaceIndices.size()) - 1))
             return;
+        // Every index must name an element that exists: the arrays go to the GPU as they are, and a kernel
+        // that follows an index past its array faults. (The reference does not check.)
+        for (size_t fi = 0; fi < facePositionIndices.size(); ++fi)
+            for (int i = 0; i < 3; ++i)
+                if (facePositionIndices[fi][i] >= positions.size() || faceNormalIndices[fi][i] >= normals.size() ||
+                    faceTexCoordIndices[fi][i] >= texCoords.size()) {
+                    fail("Face " + std::to_string(fi) + " refers to a position, normal or texture coordinate that "
+                         "the file does not define.");
+                    return;
+                }
         isComplete = true;
     }
 
@@ -252,10 +269,20 @@ class OBJMesh {
   private:
     // reference mesh.h:322-381
     bool appendLight(const InputLight &in, IndexTy gi) {
+        if (gi >= grpStartFaceIndices.size() || faceNormalIndices.empty())
+            return fail("A light's material is used before a group with faces exists.");
         const IndexTy fiBeg = grpStartFaceIndices[gi];
         const IndexTy fiEnd = gi == grpStartFaceIndices.size() - 1
                                   ? static_cast<IndexTy>(faceNormalIndices.size()) - 1 // (sic) one face short
                                   : grpStartFaceIndices[gi + 1];
+        // the group's faces are read here, while the file is still being parsed: they and their vertices
+        // must have come before
+        if (fiBeg > fiEnd || fiEnd > facePositionIndices.size())
+            return fail("Group " + std::to_string(gi) + " of a light holds no faces.");
+        for (IndexTy fi = fiBeg; fi < fiEnd; ++fi)
+            for (int i = 0; i < 3; ++i)
+                if (facePositionIndices[fi][i] >= positions.size())
+                    return fail("Face " + std::to_string(fi) + " of a light refers to a position that is not defined.");
         Light lht{};
         lht.type = in.type;
         lht.radiance = in.radiance;
@@ -277,6 +304,8 @@ class OBJMesh {
             lht.quad.u = detail::sub3(positions[idx[(corner + 2) % 3]], lht.quad.o);
             lht.quad.v = detail::sub3(positions[idx[corner]], lht.quad.o);
         } else {
+            if (fiEnd == fiBeg)
+                return fail("Group " + std::to_string(gi) + " of a light holds no faces.");
             const float div = 3.f * static_cast<float>(fiEnd - fiBeg);
             vec3 o(0.f, 0.f, 0.f);
             for (IndexTy fi = fiBeg; fi < fiEnd; ++fi)

@@ -71,6 +71,14 @@ class LBVH : Noncopyable {
         clear();
         const uint32_t V = static_cast<uint32_t>(inputMesh.positions.size());
         const uint32_t N = static_cast<uint32_t>(inputMesh.facePositionIndices.size());
+        // the kernels follow these indices into the positions: one past the array is a GPU memory fault
+        for (uint32_t fi = 0; fi < N; ++fi)
+            for (int i = 0; i < 3; ++i)
+                if (inputMesh.facePositionIndices[fi][i] >= V) {
+                    std::cerr << ErrTag << " Face " << fi << " refers to position "
+                              << inputMesh.facePositionIndices[fi][i] << ", the mesh has " << V << ".\n";
+                    return;
+                }
         kk_lbvh_ws_layout lay;
         if (!KOUEK_HIP_CHECK(ErrTag.data(), kk_lbvh_workspace_layout(N, V, 0, &lay)))
             return;

@@ -89,6 +89,26 @@ class RayTracer : Noncopyable {
     };
 
     void SetMesh(const InputMesh &in) {
+        // The kernels follow the mesh's indices into its arrays, and one past an array is a GPU memory fault:
+        // a mesh whose indices do not fit its arrays is refused here. (The reference uploads it as it is.)
+        if (in.faceNormalIndices.size() != in.facePositionIndices.size() ||
+            in.faceTexCoordIndices.size() != in.facePositionIndices.size()) {
+            std::cerr << ErrTag << " SetMesh: the three face index arrays differ in length.\n";
+            return;
+        }
+        for (size_t fi = 0; fi < in.facePositionIndices.size(); ++fi)
+            for (int i = 0; i < 3; ++i)
+                if (in.facePositionIndices[fi][i] >= in.positions.size() ||
+                    in.faceNormalIndices[fi][i] >= in.normals.size() ||
+                    (!in.texCoords.empty() && in.faceTexCoordIndices[fi][i] >= in.texCoords.size())) {
+                    std::cerr << ErrTag << " SetMesh: face " << fi
+                              << " refers to a position, normal or texture coordinate the mesh does not have.\n";
+                    return;
+                }
+        if (in.materials.size() < (in.groupStartFaceIndices.empty() ? 1u : in.groupStartFaceIndices.size())) {
+            std::cerr << ErrTag << " SetMesh: fewer materials than groups.\n";
+            return;
+        }
         std::vector<Triangle> tris(in.facePositionIndices.size());
         for (size_t fi = 0; fi < tris.size(); ++fi) {
             tris[fi].normIdx = in.faceNormalIndices[fi];

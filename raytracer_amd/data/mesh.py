@@ -113,7 +113,7 @@ class OBJMesh:
 
     def _load(self, path: str, input_lights):
         try:
-            fh = open(path, "r")
+            fh = open(path, "r", errors="replace")
         except OSError:
             return self._fail(f'Cannot open file at "{path}".')
         prev_is_light, prev_light = False, None
@@ -134,6 +134,9 @@ class OBJMesh:
                     if not m:
                         return self._fail(f"Failed parsing line {ln}.")
                     v = [int(x) - 1 for x in m.groups()]
+                    # indices count from one and fit 32 bits (the reference lets a zero wrap to 2^32 - 1)
+                    if min(v) < 0 or max(v) >= 0xFFFFFFFF:
+                        return self._fail(f"Failed parsing line {ln}.")
                     self.face_position_indices.append((v[0], v[3], v[6]))
                     self.face_tex_coord_indices.append((v[1], v[4], v[7]))
                     self.face_normal_indices.append((v[2], v[5], v[8]))
@@ -151,6 +154,8 @@ class OBJMesh:
                     if not self._load_mtl(os.path.join(os.path.dirname(path), rest)):
                         return False
                 elif name == "usemtl":
+                    if not self.grp_start_face_indices:  # a material belongs to a group
+                        return self._fail(f"Failed parsing line {ln}.")
                     if prev_is_light and not self._append_light(prev_light, len(self.grp_start_face_indices) - 2):
                         return False
                     gi = len(self.grp_start_face_indices) - 1
@@ -162,6 +167,15 @@ class OBJMesh:
                         prev_light = input_lights[rest]
         if prev_is_light and not self._append_light(prev_light, len(self.grp_start_face_indices) - 1):
             return False
+        # Every index must name an element that exists: the arrays go to the GPU as they are, and a kernel
+        # that follows an index past its array faults. (The reference does not check.)
+        for idx, have in ((self.face_position_indices, len(self.positions)),
+                          (self.face_normal_indices, len(self.normals)),
+                          (self.face_tex_coord_indices, len(self.tex_coords))):
+            if idx and int(np.asarray(idx, np.int64).max()) >= have:
+                fi = int(np.argmax(np.asarray(idx, np.int64).max(axis=1) >= have))
+                return self._fail(f"Face {fi} refers to a position, normal or texture coordinate that the "
+                                  "file does not define.")
         self.is_complete = True
         return True
 
@@ -171,7 +185,16 @@ class OBJMesh:
         pos = np.asarray(self.positions, np.float32).reshape(-1, 3)
         fpi = self.face_position_indices
         gs = self.grp_start_face_indices
+        if gi < 0 or gi >= len(gs) or not self.face_normal_indices:
+            return self._fail("A light's material is used before a group with faces exists.")
         fi_end = len(self.face_normal_indices) - 1 if gi == len(gs) - 1 else gs[gi + 1]
+        # the group's faces are read here, while the file is still being parsed: they and their vertices
+        # must have come before
+        if gs[gi] > fi_end or fi_end > len(fpi) or (ltype != QUAD and fi_end == gs[gi]):
+            return self._fail(f"Group {gi} of a light holds no faces.")
+        for fi in range(gs[gi], fi_end):
+            if max(fpi[fi]) >= pos.shape[0]:
+                return self._fail(f"Face {fi} of a light refers to a position that is not defined.")
         lht = ObjLight(type=ltype, radiance=np.asarray(radiance, np.float32))
         if ltype == QUAD:
             if fi_end - gs[gi] != 2:
@@ -212,7 +235,7 @@ class OBJMesh:
 
     def _load_mtl(self, path: str) -> bool:
         try:
-            fh = open(path, "r")
+            fh = open(path, "r", errors="replace")
         except OSError:
             return self._fail(f'Cannot open file at "{path}".')
         self.name2mtls = {}
@@ -231,6 +254,8 @@ class OBJMesh:
                     if rest in self.name2mtls:
                         return self._fail(f"Failed parsing line {ln}.")
                     cur = self.name2mtls[rest] = ObjMaterial()
+                elif cur is None:  # a property before the first newmtl
+                    return self._fail(f"Failed parsing line {ln}.")
                 elif name in ("Ni", "Ns"):
                     f = _scan_floats(rest, 1)
                     if len(f) != 1:
@@ -249,10 +274,13 @@ def parse_scene_xml(path: str):
     `<light mtlname= type= radiance=>` elements. Returns None if any required piece is missing."""
     import xml.etree.ElementTree as ET
 
-    text = open(path, "r").read()
-    # the files hold several top-level elements; wrap them so a strict parser accepts them
-    body = re.sub(r"<\?xml[^>]*\?>", "", text)
-    root = ET.fromstring("<scene>" + body + "</scene>")
+    try:
+        text = open(path, "r", errors="replace").read()
+        # the files hold several top-level elements; wrap them so a strict parser accepts them
+        body = re.sub(r"<\?xml[^>]*\?>", "", text)
+        root = ET.fromstring("<scene>" + body + "</scene>")
+    except (OSError, ET.ParseError, ValueError):  # unreadable or not XML: no scene description
+        return None
     cam = root.find("camera")
     if cam is None or cam.get("type") != "perspective":
         return None

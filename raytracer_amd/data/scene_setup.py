@@ -23,6 +23,8 @@ def load_obj_scene(obj_path: str) -> dict:
     ni, ns = np.zeros(G, np.float32), np.zeros(G, np.float32)
     emission = np.zeros((G, 3), np.float32)
     for gi, name in m.grp2mtl_names.items():
+        if name not in m.name2mtls:  # (the reference's application throws out of .at() here)
+            raise ValueError(f'group {gi} uses the material "{name}", which the material library does not define')
         mt = m.name2mtls[name]
         kd[gi], ks[gi], tr[gi], ni[gi], ns[gi] = mt.kd, mt.ks, mt.tr, mt.ni, mt.ns
         if name in scn["lights"]:

@@ -41,7 +41,7 @@ class TransferFunction:
         self.empty_scalar_ranges = None
         if path is not None:
             try:
-                text = open(path, "r").read()
+                text = open(path, "r", errors="replace").read()
             except OSError:
                 self.error = f'Cannot open file at "{path}".'
                 return

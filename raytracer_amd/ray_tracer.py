@@ -226,6 +226,17 @@ class RayTracer:
         materials = (materials if isinstance(materials, np.ndarray)
                      else stack_structs(materials, MATERIAL_DTYPE))
         assert lights.dtype.itemsize == 80 and materials.dtype.itemsize == 64, "struct layout lost"
+        # the kernels follow these indices into the arrays below: one past an array is a GPU memory fault
+        if n:
+            for what, idx, have in (("position", fpi, np.asarray(positions).reshape(-1, 3).shape[0]),
+                                    ("normal", tris["normIdx"], np.asarray(normals).reshape(-1, 3).shape[0]),
+                                    ("material", tris["grpIdx"], int(materials.size))):
+                if int(idx.max()) >= have:
+                    raise ValueError(f"a face refers to {what} {int(idx.max())}, the mesh has {have}")
+            n_tex = np.asarray(tex_coords).reshape(-1, 2).shape[0] if len(tex_coords) else 0
+            if n_tex and int(tris["texCoordIdx"].max()) >= n_tex:
+                raise ValueError(f"a face refers to texture coordinate {int(tris['texCoordIdx'].max())}, "
+                                 f"the mesh has {n_tex}")
 
         sizes = _lib.PtSceneSizes()
         sizes.face_num, sizes.vert_num = n, int(np.asarray(positions).reshape(-1, 3).shape[0])

@@ -44,6 +44,8 @@ int main(int argc, char **argv) {
                              : RayTracer::Light::CreateSphere(l.sphere.r, l.sphere.o, l.radiance));
     std::vector<RayTracer::Material> materials(mesh.GetGroupToMaterialNames().size());
     for (auto &[gi, name] : mesh.GetGroupToMaterialNames()) {
+        if (mesh.GetNameToMaterials().find(name) == mesh.GetNameToMaterials().end() || gi >= materials.size())
+            return 8; // a group's material that the library does not define
         const auto &m = mesh.GetNameToMaterials().at(name);
         auto itr = cfg.lights.find(name);
         materials[gi] = itr == cfg.lights.end()

@@ -130,3 +130,81 @@ def test_cpp_obj_loader_refuses_what_the_reference_refuses(veach, tmp_path):
                             str(tmp_path / "t.txt"), str(tmp_path / "o")], capture_output=True, text=True)
         assert r.returncode == 4 and "Failed parsing line" in r.stderr, (bad, r.returncode, r.stderr)
         assert not OBJMesh(str(p), {}).is_complete
+
+
+# What the reference reads without a check and a GPU kernel would then follow past an array: both loaders
+# refuse it with a message instead (and neither crashes on it).
+MALFORMED = {
+    "index_zero": ("obj", lambda t: t + "f 0/1/1 1/1/1 2/2/2\n"),
+    "index_past_the_positions": ("obj", lambda t: t + "f 99999999/1/1 1/1/1 2/2/2\n"),
+    "index_past_the_normals": ("obj", lambda t: t + "f 1/1/99999999 1/1/1 2/2/2\n"),
+    "index_past_the_texture_coordinates": ("obj", lambda t: t + "f 1/99999999/1 1/1/1 2/2/2\n"),
+    "index_wider_than_32_bits": ("obj", lambda t: t + "f 4294967297/1/1 1/1/1 2/2/2\n"),
+    "material_before_any_group": ("obj", lambda t: t.replace("g group0\n", "", 1)),
+    "light_group_before_its_vertices": ("obj", lambda t: "\n".join(
+        [l for l in t.split("\n") if not l.startswith("v ")] + [l for l in t.split("\n") if l.startswith("v ")]) + "\n"),
+    "property_before_newmtl": ("mtl", lambda t: "Kd 1 1 1\n" + t),
+}
+
+
+@pytest.mark.parametrize("case", sorted(MALFORMED))
+def test_loaders_refuse_indices_and_orders_a_kernel_could_not_follow(veach, tmp_path, case):
+    obj = write_scene(veach, str(tmp_path))
+    which, change = MALFORMED[case]
+    path = obj[:-3] + which
+    text = open(path).read()
+    changed = change(text)
+    assert changed != text
+    open(path, "w").write(changed)
+    (tmp_path / "v.raw").write_bytes(np.zeros(8, np.uint8).tobytes())
+    (tmp_path / "t.txt").write_text(README_HEAD_TF)
+    (tmp_path / "o").mkdir(exist_ok=True)
+    if not os.path.exists(EXE):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cpp"), "-s"])
+    r = subprocess.run([EXE, obj, str(tmp_path / "v.raw"), "2", "2", "2", "1", "2", "3",
+                        str(tmp_path / "t.txt"), str(tmp_path / "o")], capture_output=True, text=True)
+    assert r.returncode == 4 and "Error" in r.stderr, (case, r.returncode, r.stderr)
+    scn = parse_scene_xml(obj[:-4] + ".xml")
+    m = OBJMesh(obj, scn["lights"])
+    assert not m.is_complete and m.error, case
+    with pytest.raises(ValueError):
+        load_obj_scene(obj)
+
+
+def test_undefined_material_and_broken_xml_are_reported_not_thrown(veach, tmp_path):
+    obj = write_scene(veach, str(tmp_path))
+    t = open(obj).read().replace("usemtl mtl1\n", "usemtl nosuch\n", 1)
+    open(obj, "w").write(t)
+    with pytest.raises(ValueError, match="nosuch"):
+        load_obj_scene(obj)
+    open(obj[:-4] + ".xml", "w").write("<camera type=\"perspective\" width=\"4\"")
+    assert parse_scene_xml(obj[:-4] + ".xml") is None
+    with pytest.raises(ValueError):
+        load_obj_scene(obj)
+
+
+def test_host_classes_refuse_indices_past_their_arrays(veach):
+    """LBVH.BuildFrom and RayTracer.SetMesh check the mesh before anything reaches the GPU (this test
+    needs none: the refusal comes first)."""
+    from raytracer_amd.lbvh import LBVH
+    pos = veach["positions"]
+    tri = veach["face_position_indices"].copy()
+    tri[7, 1] = pos.shape[0]  # one past the last position
+    bvh = LBVH("cuda:0")
+    bvh.BuildFrom(pos, tri)
+    assert not bvh.IsComplete()
+    tri[7, 1] = 0xFFFFFFFF
+    bvh.BuildFrom(pos, tri)
+    assert not bvh.IsComplete()
+    tracer = rt.RayTracer("cuda:0")
+    arr = veach_arrays(veach)
+    fni = veach["face_normal_indices"].copy()
+    fni[3, 2] = veach["normals"].shape[0]
+    with pytest.raises(ValueError, match="normal"):
+        tracer.SetMesh(pos, veach["normals"], veach["tex_coords"], veach["grp_start_face_indices"],
+                       veach["face_position_indices"], fni, veach["face_tex_coord_indices"],
+                       arr["lights"], arr["materials"])
+    with pytest.raises(ValueError, match="material"):
+        tracer.SetMesh(pos, veach["normals"], veach["tex_coords"], veach["grp_start_face_indices"],
+                       veach["face_position_indices"], veach["face_normal_indices"],
+                       veach["face_tex_coord_indices"], arr["lights"], arr["materials"][:2])
