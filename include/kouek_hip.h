@@ -175,7 +175,11 @@ enum {
  * caller) accumulates node boxes fetched, triangles tested, rays traced. d_workspace holds the ray
  * queue head (kk_closest_hit_workspace_bytes()). internal_nodes must be 16-byte aligned, as the
  * reference's KOUEK_CUDA_ALIGN makes them. Same slab and triangle arithmetic as
- * include/cg/ray.h:29-58. */
+ * include/cg/ray.h:29-58.
+ * A ray with a NaN or an infinite component reports a miss (here and in kk_closest_hit_accel and the
+ * path tracer's walks). The reference's slab test calls every box "not missed" for such a ray, so it
+ * walks the whole tree and keeps nothing (no NaN distance is the smaller one; only an infinite direction
+ * can leave it a spurious hit at t = 0): the same answer without a visit of every node per bad ray. */
 size_t kk_closest_hit_workspace_bytes(void);
 int kk_closest_hit(const kk_lbvh_device_data *d_lbvh, const float *d_positions,
                    const uint32_t *d_face_pos_idx, const float *d_rays, uint32_t ray_num, float *d_t,

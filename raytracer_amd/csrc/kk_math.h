@@ -116,6 +116,15 @@ struct Ray {
     f3 pos, dir;
 };
 
+// A ray with a NaN or an infinite component: every comparison of the reference's slab test comes out
+// "not missed" for it, so the reference walks the whole tree and finds nothing it can keep (a NaN
+// distance is never the smaller one; only an infinite direction can leave it a spurious hit at t = 0).
+// The walks here give such a ray a miss at once instead of visiting every node for it.
+KK_HD bool ray_is_finite(const f3 &pos, const f3 &dir) {
+    return fabsf(pos.x) <= FloatMax && fabsf(pos.y) <= FloatMax && fabsf(pos.z) <= FloatMax &&
+           fabsf(dir.x) <= FloatMax && fabsf(dir.y) <= FloatMax && fabsf(dir.z) <= FloatMax;
+}
+
 // include/cg/ray.h:29-45: six divisions, glm min/max nesting, tEnter clamped at 0.
 KK_HD void HitAABB(const Ray &r, const AABB &b, float &tEnter, float &tExit) {
     float h0 = (b.minPos.x - r.pos.x) / r.dir.x;

@@ -117,7 +117,7 @@ KK_D bool occluded(const trav::Scene &s, const Ray &ray, float tMax, uint32_t *s
     const NodeData root = load_node(s.nodes, 0);
     float tEnter, tExit;
     HitAABB(ray, root.box, tEnter, tExit);
-    if (tEnter > tExit)
+    if (tEnter > tExit || !ray_is_finite(ray.pos, ray.dir))
         return false;
     uint32_t lft = root.lft, rht = root.rht;
     int sp = 0;
@@ -493,7 +493,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(WAVES, 
         HitAABB(Ray{pos, dir}, rootBox, tEnter, tExit);
         prepare_ray(pos, dir, ray, sg, mode);
         w.start(sg.oct);
-        if (tEnter > tExit)
+        if (tEnter > tExit || !ray_is_finite(pos, dir))
             stage = closest ? ST_DONE_C : ST_DONE_S_CLEAR;
         else
             stage = closest ? ST_WALK_C : ST_WALK_S;

@@ -930,7 +930,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(5, 5)))
                     restart();
                     float tEnter, tExit;
                     HitAABB(Ray{ray.pos, ray.dir}, rootBox, tEnter, tExit);
-                    if (tEnter > tExit) { // misses the scene: retire at the next refill
+                    if (tEnter > tExit || !ray_is_finite(ray.pos, ray.dir)) { // misses the scene (or is no ray): retire at the next refill
                         active = false;
                         finished = true;
                     } else {

@@ -105,7 +105,7 @@ KK_D void walk_begin(const Scene &s, const Ray &ray, Walk &w, Hit &best, uint32_
     w.sp = 0;
     w.lft = root.lft;
     w.rht = root.rht;
-    w.done = tEnter > tExit;
+    w.done = tEnter > tExit || !ray_is_finite(ray.pos, ray.dir);
 }
 
 // Visits one internal node: tests its leaf children's triangles, box-tests its internal children,

@@ -627,7 +627,7 @@ __device__ __forceinline__ Hit8 closest_hit_lane(const View &v, Ray r, const Lan
     rootBox.maxPos = {v.hdr->rootBox[3], v.hdr->rootBox[4], v.hdr->rootBox[5]};
     float tEnter, tExit;
     HitAABB(r, rootBox, tEnter, tExit);
-    if (tEnter > tExit)
+    if (tEnter > tExit || !ray_is_finite(r.pos, r.dir))
         return best;
     const kk_lbvh_node *nodes = v.hdr->nodes;
     const char *wideBytes = reinterpret_cast<const char *>(v.wide);
@@ -682,7 +682,7 @@ __device__ __forceinline__ bool occluded_lane(const View &v, Ray r, float tMax, 
     rootBox.maxPos = {v.hdr->rootBox[3], v.hdr->rootBox[4], v.hdr->rootBox[5]};
     float tEnter, tExit;
     HitAABB(r, rootBox, tEnter, tExit);
-    if (tEnter > tExit)
+    if (tEnter > tExit || !ray_is_finite(r.pos, r.dir))
         return false;
     const kk_lbvh_node *nodes = v.hdr->nodes;
     const char *wideBytes = reinterpret_cast<const char *>(v.wide);

@@ -1,0 +1,94 @@
+"""Inputs no renderer should see, which must neither fault nor stall the GPU: rays and vertices with NaN
+or infinite components, triangles of zero area, a mesh of one repeated vertex. The reference's slab test
+calls every box "not missed" for a non-finite ray (include/cg/ray.h:29-45: its comparisons are all false),
+walks the whole tree and keeps nothing; the walks here report that miss at once. Scenes are small, so a
+walk of every node would still end."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from raytracer_amd import synthetic as syn  # noqa: E402
+from raytracer_amd.lbvh import LBVH  # noqa: E402
+from raytracer_amd.ray_tracer import closest_hit  # noqa: E402
+
+DEV = "cuda:0"
+MISS = 0xFFFFFFFF
+
+
+def _trace(bvh, rays, **kw):
+    got = closest_hit(bvh, torch.from_numpy(rays).to(DEV), **kw)
+    torch.cuda.synchronize()
+    return got[0].cpu().numpy(), got[2].cpu().numpy().view(np.uint32)
+
+
+@pytest.mark.parametrize("layout", ["trace", "build"])
+def test_non_finite_rays_miss_and_finite_rays_are_untouched(oracle, layout):
+    pos, tri = syn.triangle_soup(20_000, seed=4)
+    bvh = LBVH(DEV)
+    bvh.BuildFrom(pos, tri)
+    rays = syn.incoherent_rays(4096, seed=9)
+    clean_t, clean_prim = _trace(bvh, rays, layout=layout)
+    bad = rays.copy()
+    rng = np.random.default_rng(1)
+    rows = rng.choice(4096, 300, replace=False)
+    vals = [np.nan, np.inf, -np.inf]
+    for j, r in enumerate(rows):
+        bad[r, j % 6] = vals[j % 3]
+    bad[rows[0]] = np.nan
+    bad[rows[1], 3:] = 0.0  # no direction at all: finite, the walk's own business
+    t, prim = _trace(bvh, bad, layout=layout)
+    is_bad = np.zeros(4096, bool)
+    is_bad[rows] = True
+    is_bad[rows[1]] = False
+    assert (prim[is_bad] == MISS).all()
+    assert (t[is_bad] == np.float32(3.402823466e+38)).all()
+    keep = ~is_bad
+    keep[rows[1]] = False
+    np.testing.assert_array_equal(prim[keep], clean_prim[keep])
+    assert t[keep].tobytes() == clean_t[keep].tobytes()
+    # the checker walks the whole tree for a NaN ray and keeps nothing either
+    ref = oracle.lbvh_build(pos, tri, refit_mode=1)
+    nan_rows = rows[[j for j in range(len(rows)) if j % 3 == 0 and j > 1]][:40]
+    _, _, oprim, _ = oracle.closest_hit(ref, pos, tri, bad[nan_rows])
+    assert (np.asarray(oprim).view(np.uint32) == MISS).all()
+
+
+def test_mesh_with_non_finite_and_degenerate_triangles_builds_and_traces():
+    pos, tri = syn.triangle_soup(30_000, seed=6)
+    pos = pos.copy()
+    rng = np.random.default_rng(2)
+    v = rng.choice(pos.shape[0], 60, replace=False)
+    pos[v[:20], rng.integers(0, 3, 20)] = np.nan
+    pos[v[20:40], rng.integers(0, 3, 20)] = np.inf
+    pos[v[40:50]] = pos[v[50:60]]  # (some vertices repeated)
+    f = rng.choice(tri.shape[0], 200, replace=False)
+    tri = tri.copy()
+    tri[f[:100], 1] = tri[f[:100], 0]  # zero-area triangles: two corners the same ...
+    tri[f[100:], 1] = tri[f[100:], 0]
+    tri[f[100:], 2] = tri[f[100:], 0]  # ... or all three
+    bvh = LBVH(DEV)
+    bvh.BuildFrom(pos, tri)
+    assert bvh.IsComplete()
+    h = bvh.to_host()
+    assert h["N"] == tri.shape[0] and 1 <= h["M"] <= h["N"]
+    assert sorted(h["faces"].tolist()) == list(range(tri.shape[0]))
+    rays = syn.incoherent_rays(8192, seed=3)
+    for layout in ("trace", "build"):
+        t, prim = _trace(bvh, rays, layout=layout)
+        hit = prim != MISS
+        assert (prim[hit] < tri.shape[0]).all() and np.isfinite(t[hit]).all() and (t[hit] >= 0).all()
+
+
+def test_mesh_of_one_repeated_vertex():
+    pos = np.full((3000, 3), 0.25, np.float32)
+    tri = np.arange(3000, dtype=np.uint32).reshape(-1, 3)
+    bvh = LBVH(DEV)
+    bvh.BuildFrom(pos, tri)
+    assert bvh.IsComplete() and bvh.GetDeviceData()["compactedFaceNum"] == 1
+    rays = syn.incoherent_rays(1024, seed=5)
+    for layout in ("trace", "build"):
+        t, prim = _trace(bvh, rays, layout=layout)
+        assert (prim == MISS).all()
