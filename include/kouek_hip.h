@@ -52,6 +52,12 @@ int kk_stream_synchronize(void *stream);
  * their own outputs and workspaces run side by side and fill each other's idle tails (4K DVR: 1391
  * frames/s against 949 one after the other). No counterpart in the reference, which renders one frame
  * at a time on the default stream. */
+/* For a mesh that already lives on the device: KK_ERR_INVALID when some d_indices[i] >= limit (the kernels
+ * follow face indices into positions / normals / texture coordinates / materials without a check of their
+ * own, and one past an array is a GPU memory fault). d_word: four bytes of device memory for the result;
+ * waits for `stream`. Not part of the reference, which uploads a mesh as its loader left it; the C++ and
+ * Python host classes make the same check on the host before they upload. */
+int kk_check_indices(const uint32_t *d_indices, size_t count, uint32_t limit, uint32_t *d_word, void *stream);
 int kk_stream_create(void **out_stream);
 int kk_stream_destroy(void *stream);
 

@@ -117,6 +117,7 @@ def _declare(l):
     l.kk_debug_sort_force_error.argtypes = [i32]
     l.kk_closest_hit_accel_status.argtypes = [vp, u32, vp]
     l.kk_dvr_tile_order_status.argtypes = [vp, u32, vp]
+    l.kk_check_indices.argtypes = [vp, sz, u32, vp, vp]
     l.kk_lbvh_workspace_layout.argtypes = [u32, u32, u32, C.POINTER(LbvhWsLayout)]
     l.kk_lbvh_build.argtypes = [vp, u32, vp, u32, vp, vp, vp, vp, vp, sz, u32, vp]
     l.kk_closest_hit_workspace_bytes.restype = sz

@@ -78,3 +78,40 @@ extern "C" int kk_stream_destroy(void *stream) {
         KK_HIP_TRY(hipStreamDestroy(static_cast<hipStream_t>(stream)));
     return KK_OK;
 }
+
+// ---- index check for meshes that already live on the device ------------------------------------------
+namespace kk {
+__global__ __launch_bounds__(256) void max_index_kernel(const uint32_t *__restrict__ idx, size_t count,
+                                                        uint32_t *__restrict__ out) {
+    uint32_t m = 0;
+    for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < count; i += gridDim.x * 256ull)
+        m = idx[i] > m ? idx[i] : m;
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t other = __shfl_xor(m, o, 64);
+        m = other > m ? other : m;
+    }
+    if ((threadIdx.x & 63) == 0)
+        atomicMax(out, m);
+}
+} // namespace kk
+
+extern "C" int kk_check_indices(const uint32_t *d_indices, size_t count, uint32_t limit, uint32_t *d_word,
+                                void *stream_) {
+    KK_REQUIRE(d_indices != nullptr && d_word != nullptr, "null pointer");
+    if (count == 0)
+        return KK_OK;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    KK_HIP_TRY(hipMemsetAsync(d_word, 0, sizeof(uint32_t), stream));
+    const size_t want = (count + 255) / 256;
+    const uint32_t grid = static_cast<uint32_t>(want < 2048 ? want : 2048);
+    kk::max_index_kernel<<<grid, 256, 0, stream>>>(d_indices, count, d_word);
+    KK_LAUNCH_CHECK();
+    uint32_t top = 0;
+    KK_HIP_TRY(hipMemcpyAsync(&top, d_word, sizeof(top), hipMemcpyDeviceToHost, stream));
+    KK_HIP_TRY(hipStreamSynchronize(stream));
+    if (top >= limit) {
+        kk::set_error("an index of %u where the array it points into has %u elements", top, limit);
+        return KK_ERR_INVALID;
+    }
+    return KK_OK;
+}

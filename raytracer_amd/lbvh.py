@@ -119,9 +119,15 @@ class LBVH:
             raise _lib.KoukeError("empty mesh: the build needs at least one face")
         # the kernels follow these indices into the positions: one past the array is a GPU memory fault
         # (as unsigned numbers, so that a negative int32 view of a large index counts as large)
-        top = int(tri_t.view(torch.int32).to(torch.int64).bitwise_and(0xFFFFFFFF).max())
-        if top >= V:
-            raise _lib.KoukeError(f"a face refers to position {top}, the mesh has {V}")
+        if tri_t.is_cuda:
+            word = torch.empty(1, dtype=torch.int32, device=tri_t.device)
+            with torch.cuda.device(tri_t.device):
+                _lib.check(l.kk_check_indices(tri_t.contiguous().data_ptr(), 3 * N, V, word.data_ptr(),
+                                              _lib.current_stream_ptr()), "kk_check_indices")
+        else:
+            top = int(tri_t.view(torch.int32).to(torch.int64).bitwise_and(0xFFFFFFFF).max())
+            if top >= V:
+                raise _lib.KoukeError(f"a face refers to position {top}, the mesh has {V}")
         self.alloc_blob(N, V)
         self.d_positions.copy_(pos_t.to(torch.float32))
         self.d_face_pos_idx.copy_(tri_t.view(torch.int32) if tri_t.dtype != torch.int32 else tri_t)

@@ -149,3 +149,21 @@ def test_volumes_without_a_tree_are_refused_and_a_solid_volume_renders(oracle, c
     d = np.abs(got[..., :3].astype(int) - want[..., :3].astype(int))
     assert d.max() <= 1 and float((d.max(axis=2) > 0).mean()) <= 0.01
     assert got[..., 3].max() > 0
+
+
+def test_device_resident_mesh_with_an_index_past_the_positions_is_refused(capsys):
+    """BuildFrom on torch device tensors checks the indices on the device (kk_check_indices) before the
+    build is enqueued."""
+    pos, tri = syn.triangle_soup(5_000, seed=8)
+    d_pos = torch.from_numpy(pos).to(DEV)
+    d_tri = torch.from_numpy(tri.view(np.int32).copy()).to(DEV)
+    bvh = LBVH(DEV)
+    bvh.BuildFrom(d_pos, d_tri)
+    assert bvh.IsComplete()
+    d_tri[1234, 2] = pos.shape[0]
+    bvh.BuildFrom(d_pos, d_tri)
+    assert not bvh.IsComplete()
+    d_tri[1234, 2] = -1  # 0xFFFFFFFF
+    bvh.BuildFrom(d_pos, d_tri)
+    assert not bvh.IsComplete()
+    assert "an index of" in capsys.readouterr().err
