@@ -2,6 +2,9 @@
 import os, sys, hashlib
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
+from raytracer_amd import _lib
+if len(sys.argv) > 2 and sys.argv[2] != "-":
+    _lib.LIB_PATH = os.path.abspath(sys.argv[2])
 from raytracer_amd import synthetic as syn
 from raytracer_amd.lbvh import LBVH
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
