@@ -60,3 +60,48 @@ def test_product_package_never_imports_the_checker():
                 if re.search(r"\boracle\b|kkoracle|libkkref", text):
                     offenders.append(os.path.relpath(os.path.join(dirpath, fn), ROOT))
     assert not offenders, offenders
+
+
+_NULL_ARGS_CHILD = r"""
+import ctypes, sys
+l = ctypes.CDLL(sys.argv[1])
+for item in sys.argv[2:]:
+    name, n = item.split(":")
+    f = getattr(l, name)
+    f.restype = ctypes.c_long
+    print(name, flush=True)
+    rc = f(*([ctypes.c_void_p(0)] * int(n)))
+    print("=", rc, flush=True)
+"""
+
+
+def test_every_entry_point_refuses_null_and_zero_arguments():
+    """All-zero arguments (null pointers, zero sizes) come back as an error code or a harmless size, never
+    as a crash: a host that mis-wires a call must get a message, not a dead process. One child process
+    makes the calls in turn and names each before it is made. (Entry points that take a struct by value,
+    free or destroy a handle, or are plain setters are left out.)"""
+    import subprocess
+    import sys
+    from raytracer_amd import _lib
+    text = open(os.path.join(ROOT, "include", "kouek_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    protos = re.findall(r"\b(?:int|size_t|uint32_t)\s*(kk_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S)
+    skip = {"kk_free", "kk_stream_destroy", "kk_comm_destroy", "kk_set_device", "kk_stream_synchronize",
+            "kk_memset", "kk_memcpy_h2d", "kk_memcpy_d2h", "kk_malloc", "kk_stream_create"}
+    items = []
+    for name, params in protos:
+        plist = [p.strip() for p in params.split(",")] if params.strip() not in ("", "void") else []
+        by_value = any(re.search(r"\bkk_[a-z_]+\s+[a-z_]+$", p) and "*" not in p for p in plist)
+        if name not in skip and not by_value:
+            items.append(f"{name}:{len(plist)}")
+    assert len(items) >= 60
+    r = subprocess.run([sys.executable, "-c", _NULL_ARGS_CHILD, _lib.LIB_PATH] + items, capture_output=True,
+                       text=True, timeout=300)
+    called = [l for l in r.stdout.split("\n") if l.startswith("kk_")]
+    assert r.returncode == 0, f"crashed in {called[-1] if called else '?'}: {r.stderr[-500:]}"
+    assert len(called) == len(items)
+    # calls that take pointers report an error (-1 = KK_ERR_INVALID as a 32-bit int, or another KK_ERR_*)
+    results = dict(zip(called, [int(l[2:]) for l in r.stdout.split("\n") if l.startswith("= ")]))
+    for name in ("kk_lbvh_build", "kk_closest_hit", "kk_closest_hit_accel", "kk_pt_render_sample",
+                 "kk_dvr_render_u8", "kk_vdb_classify_u8", "kk_sort_pairs_u32", "kk_check_indices"):
+        assert results[name] & 0xFFFFFFFF >= 0xFFFFFFF0, (name, results[name])
