@@ -108,6 +108,7 @@ __global__ __launch_bounds__(THREADS) void build_setup_kernel(
     if (tid == 0) {
         topCount[0] = 0u;
         topCount[1] = 0u; // the run-head pass's ticket counter (ticketed mode)
+        topCount[2] = 0u; // workgroups of block_totals that are through with level 3
     }
     float mn[3] = {FloatMax, FloatMax, FloatMax};
     float mx[3] = {FloatMin, FloatMin, FloatMin};
@@ -786,20 +787,57 @@ __global__ __launch_bounds__(REFIT_THREADS) void refit_window_kernel(
 }
 
 // Totals of aligned blocks of 32^l leaves, l >= 3, each the in-order fold of its 32 children of
-// level l - 1. One workgroup: the levels above a window hold a few thousand entries in all.
-__global__ __launch_bounds__(1024) void block_totals_kernel(
-    const kk_lbvh_device_data *__restrict__ hdr, float *totals, TotalsLayout tl) {
-    const uint32_t M = hdr->compacted_face_num;
-    for (uint32_t l = 3; l <= tl.levels; ++l) {
-        const uint64_t unit = 1ull << (RADIX_LOG * l);
-        const uint32_t full = static_cast<uint32_t>(M / unit); // only whole blocks are ever used
-        for (uint32_t b = threadIdx.x; b < full; b += blockDim.x) {
-            AABB acc = AABB::Initial();
-            const float *src = totals + 6 * (tl.start[l - 1] + 32ull * b);
-            for (int j = 0; j < 32; ++j)
-                acc.Expand(load_box(src + 6 * j));
-            store_box(totals + 6 * (tl.start[l] + b), acc);
+// level l - 1. Thirty-two lanes per block: lane j loads child j and the lanes' boxes are folded in lane
+// order (the left operand is kept on ties, so this is the left-to-right fold). Level 3 is spread over the
+// grid; the levels above it (a few entries in all) are made by the workgroup that finishes level 3 last.
+constexpr int TOTALS_THREADS = 256, TOTALS_PER_BLOCK = TOTALS_THREADS / 32;
+__device__ __forceinline__ void fold_children_32(const float *__restrict__ children, float *__restrict__ out,
+                                                 int lane32) {
+    const float *c = children + 6 * lane32;
+    float v[6] = {c[0], c[1], c[2], c[3], c[4], c[5]};
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) {
+        float r[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+            r[k] = __shfl_down(v[k], o, 32);
+        if (lane32 + o < 32) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                v[k] = fold_min(v[k], r[k]);
+                v[3 + k] = fold_max(v[3 + k], r[3 + k]);
+            }
         }
+    }
+    if (lane32 == 0) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+            out[k] = v[k];
+    }
+}
+__global__ __launch_bounds__(TOTALS_THREADS) void block_totals_kernel(
+    const kk_lbvh_device_data *__restrict__ hdr, float *totals, TotalsLayout tl, uint32_t *doneCount) {
+    __shared__ uint32_t s_last;
+    const uint32_t M = hdr->compacted_face_num;
+    const int lane32 = threadIdx.x & 31, group = threadIdx.x >> 5;
+    const uint32_t full3 = static_cast<uint32_t>(M >> (RADIX_LOG * 3)); // only whole blocks are ever used
+    for (uint32_t b = blockIdx.x * TOTALS_PER_BLOCK + group; b < full3; b += gridDim.x * TOTALS_PER_BLOCK)
+        fold_children_32(totals + 6 * (tl.start[2] + 32ull * b), totals + 6 * (tl.start[3] + b), lane32);
+    if (tl.levels < 4)
+        return;
+    // the last workgroup to get here sees every level-3 total (release by each, acquire by the last)
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0)
+        s_last = atomicAdd(doneCount, 1u) == gridDim.x - 1 ? 1u : 0u;
+    __syncthreads();
+    if (s_last == 0u)
+        return;
+    __threadfence();
+    for (uint32_t l = 4; l <= tl.levels; ++l) {
+        const uint32_t full = static_cast<uint32_t>(M >> (RADIX_LOG * l));
+        for (uint32_t b = group; b < full; b += TOTALS_PER_BLOCK)
+            fold_children_32(totals + 6 * (tl.start[l - 1] + 32ull * b), totals + 6 * (tl.start[l] + b), lane32);
         __threadfence_block();
         __syncthreads();
     }
@@ -913,7 +951,7 @@ inline Ws layout(uint32_t N, uint32_t flags) {
     w.pub.node_parents = c.take(4 * n);
     w.pub.leaf_parents = c.take(4 * n);
     w.headStatus = c.take(4 * static_cast<size_t>(w.headTiles));
-    w.topCount = c.take(8); // the refit's list length; the run-head pass's ticket counter
+    w.topCount = c.take(12); // the refit's list length; the run-head pass's ticket counter; block_totals' arrivals
     w.nodeInfo = c.take(8 * n);
     w.topList = c.take(4 * n);
     w.totals = c.take(24 * totals_layout(N).boxes);
@@ -1027,7 +1065,9 @@ extern "C" int kk_lbvh_build(const float *d_positions, uint32_t vert_num,
         leafAABBs, d_out, d_nodes, nodeInfo, totals, tl, topList, topCount);
     KK_LAUNCH_CHECK();
     if (tl.levels >= 3) {
-        block_totals_kernel<<<1, 1024, 0, stream>>>(d_out, totals, tl);
+        // level 3 has at most N / 32^3 entries, eight to a workgroup
+        const uint32_t tgrid = div_up((static_cast<uint64_t>(N) >> (3 * RADIX_LOG)) + 1, TOTALS_PER_BLOCK);
+        block_totals_kernel<<<tgrid, TOTALS_THREADS, 0, stream>>>(d_out, totals, tl, topCount + 2);
         KK_LAUNCH_CHECK();
     }
     refit_span_kernel<<<REFIT_SPAN_BLOCKS, THREADS, 0, stream>>>(leafAABBs, d_out, d_nodes, nodeInfo,
