@@ -566,7 +566,9 @@ int kk_dvr_tile_order(const uint32_t *d_tile_cost, uint32_t tiles, uint32_t *d_t
                       size_t workspace_bytes, void *stream);
 /* Waits for `stream` and reports on the last kk_dvr_tile_order with this workspace: KK_ERR_DEVICE when
  * its sort gave up (kk_sort_workspace_status). d_tile_order then holds the launch order 0, 1, 2, ...
- * (written on the stream after the sort), never a non-permutation, so no tile is left unrendered. */
+ * (written on the stream after the sort), never a non-permutation, so no tile is left unrendered.
+ * (Only frames of more than 2^18 tiles go through that sort; the order of smaller ones is made by one
+ * launch that waits for nothing, and the status is then always KK_OK.) */
 int kk_dvr_tile_order_status(const void *d_workspace, uint32_t tiles, void *stream);
 /* The same frame restricted to the 16-row stripes stripe_first, stripe_first + stripe_stride, ... of
  * the image (stripe s = rows [16 s, 16 s + 16)): the share of one GPU when the image is dealt out to

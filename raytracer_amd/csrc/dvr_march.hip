@@ -1068,12 +1068,11 @@ int launch(const kk_vdb_device_data *h_vdb, const float *d_tf, const kk_dvr_para
 
 // The cost of a tile in 256 classes, sixteen to a doubling: the place of its leading one and the four bits
 // below it. A list schedule needs no finer order, and eight bits sort in one pass.
-__host__ __device__ __forceinline__ uint32_t tile_cost_class(uint32_t cost) {
+__device__ __forceinline__ uint32_t tile_cost_class(uint32_t cost) {
+    // as a float the cost (< 2^24, so exact) has the place of its leading one in the exponent and the bits
+    // below it at the top of the mantissa
     const uint32_t c = cost > 65535u ? 65535u : cost;
-    uint32_t e = 0;
-    while ((c >> (e + 1u)) != 0u)
-        ++e;
-    return (e << 4) | ((e >= 4u ? c >> (e - 4u) : c << (4u - e)) & 15u);
+    return c ? (__float_as_uint(static_cast<float>(c)) >> 19) - (127u << 4) : 0u;
 }
 // Keys for the sort that puts the costly tiles first (the cost class, complemented), and the counts of
 // their digit for the sort's pass (radix_hist.h): a few workgroups, each over a share of the tiles.
@@ -1099,6 +1098,100 @@ __global__ __launch_bounds__(THREADS) void tile_order_fixup_kernel(const uint32_
         return;
     for (uint32_t i = blockIdx.x * THREADS + threadIdx.x; i < n; i += gridDim.x * THREADS)
         order[i] = i;
+}
+
+// The whole order in one launch, for frames of up to ORDER_ONE_LAUNCH_MAX tiles: a counting sort over the 256
+// classes in which no workgroup waits for another. A workgroup places 1,024 consecutive tiles and counts for
+// itself what it has to know about the others: the classes of the tiles in front of its own and of those from
+// its own on (the times of all tiles are a few hundred KB that stay in L2). A tile's place = the start of its
+// class + the tiles of the class in front of the workgroup's + those in the waves in front of its own + those
+// in lower lanes of its wave, so tiles of one class keep their order. Nothing can give up, so there is no
+// error word to raise; the word the status call reads is cleared.
+constexpr int ORDER_THREADS = 1024;
+constexpr int ORDER_WAVES = ORDER_THREADS / 64;
+constexpr uint32_t ORDER_ONE_LAUNCH_MAX = 1u << 18;
+__global__ __launch_bounds__(ORDER_THREADS) void tile_order_kernel(const uint32_t *__restrict__ cost, uint32_t n,
+                                                                   uint32_t *__restrict__ order,
+                                                                   uint32_t *__restrict__ errorWord) {
+    __shared__ uint32_t s_count[2][256]; // classes of the tiles in front of this workgroup's / from them on
+    __shared__ uint32_t s_wave[ORDER_WAVES][256];
+    __shared__ uint32_t s_tmp[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < 2 * 256; i += ORDER_THREADS)
+        (&s_count[0][0])[i] = 0u;
+    for (int i = tid; i < ORDER_WAVES * 256; i += ORDER_THREADS)
+        (&s_wave[0][0])[i] = 0u;
+    __syncthreads();
+    const uint32_t rounds = (n + ORDER_THREADS - 1u) / ORDER_THREADS;
+    uint32_t myKey = 0u;
+    for (uint32_t r0 = 0; r0 < rounds; r0 += 4u) { // four loads in flight per thread
+        uint32_t c[4];
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; ++u) {
+            const uint32_t i = (r0 + u) * ORDER_THREADS + tid;
+            c[u] = i < n ? cost[i] : 0u;
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; ++u) {
+            const uint32_t r = r0 + u, i = r * ORDER_THREADS + tid;
+            const bool in = i < n;
+            const uint32_t key = 255u - tile_cost_class(c[u]);
+            if (r == blockIdx.x)
+                myKey = key;
+            // Most tiles of a frame are empty space and share a class: the lanes whose class is lane 0's are
+            // counted with one addition instead of one each on the same word.
+            const uint32_t first = __builtin_amdgcn_readfirstlane(key);
+            const unsigned long long same = __ballot(in && key == first);
+            uint32_t *row = s_count[r < blockIdx.x ? 0 : 1];
+            if (lane == 0 && same != 0ull)
+                atomicAdd(&row[first], static_cast<uint32_t>(__popcll(same)));
+            if (in && key != first)
+                atomicAdd(&row[key], 1u);
+        }
+    }
+    // this workgroup's tiles: rank among the tiles of the same class in lower lanes of the wave
+    const uint32_t mine = blockIdx.x * ORDER_THREADS + tid;
+    const bool valid = mine < n;
+    unsigned long long peers = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+        const bool bit = (myKey >> b) & 1u;
+        const unsigned long long bal = __ballot(bit);
+        peers &= bit ? bal : ~bal;
+    }
+    const uint32_t below = __popcll(peers & ((1ull << lane) - 1ull));
+    if (valid && below == 0u) // the lowest lane of a class counts it for the wave
+        s_wave[wave][myKey] = __popcll(peers);
+    __syncthreads();
+    if (tid < 256) {
+        const uint32_t front = s_count[0][tid], total = front + s_count[1][tid];
+        uint32_t incl = total;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = __shfl_up(incl, o, 64);
+            if (lane >= o)
+                incl += t;
+        }
+        if (lane == 63)
+            s_tmp[wave] = incl;
+        s_count[1][tid] = incl - total + front; // the class's start (less the scanning waves in front) + its tiles in front
+    }
+    __syncthreads();
+    if (tid < 256) {
+        uint32_t run = s_count[1][tid];
+        for (int w = 0; w < wave; ++w)
+            run += s_tmp[w];
+        for (int w = 0; w < ORDER_WAVES; ++w) {
+            const uint32_t cnt = s_wave[w][tid];
+            s_wave[w][tid] = run;
+            run += cnt;
+        }
+    }
+    __syncthreads();
+    if (valid)
+        order[s_wave[wave][myKey] + below] = mine;
+    if (blockIdx.x == 0 && tid == 0)
+        *errorWord = 0u;
 }
 
 struct OrderWs {
@@ -1135,6 +1228,14 @@ extern "C" int kk_dvr_tile_order(const uint32_t *d_tile_cost, uint32_t tiles, ui
     }
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     char *b = static_cast<char *>(d_workspace);
+    if (tiles <= ORDER_ONE_LAUNCH_MAX && !rsort::force_error()) {
+        uint32_t *errorWord = reinterpret_cast<uint32_t *>(b + w.sortWs + kk_sort_workspace_error_offset(tiles));
+        tile_order_kernel<<<div_up(tiles, ORDER_THREADS), ORDER_THREADS, 0, stream>>>(d_tile_cost, tiles,
+                                                                                      d_tile_order, errorWord);
+        KK_LAUNCH_CHECK();
+        return KK_OK;
+    }
+    // larger frames: keys, one pass of the radix sort, and the launch order should its look-back give up
     uint32_t *keysA = reinterpret_cast<uint32_t *>(b + w.keysA);
     uint32_t *ghist = nullptr;
     const int rc = rsort::sort_prepare(b + w.sortWs, w.sortWsBytes, tiles, stream, &ghist);

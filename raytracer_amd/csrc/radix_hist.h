@@ -26,6 +26,8 @@ int sort_pairs(uint32_t *keysA, uint32_t *keysB, uint32_t *valsA, uint32_t *vals
 
 // Ticketed mode (kk_sort_set_ticketed): tiles take tickets instead of being their workgroup's index.
 bool ticketed();
+// The test hook that raises the error word after every sort (kk_debug_sort_force_error) is on.
+bool force_error();
 
 // lds: DIGITS * 256 words of the workgroup's LDS
 template <int DIGITS> __device__ __forceinline__ void hist_clear(uint32_t *lds, int tid, int threads) {

@@ -279,6 +279,7 @@ static std::atomic<int> g_ticketed{0};
 static std::atomic<int> g_forceError{0};
 
 bool ticketed() { return g_ticketed.load(std::memory_order_relaxed) != 0; }
+bool force_error() { return g_forceError.load(std::memory_order_relaxed) != 0; }
 
 struct SortWs {
     size_t ghist, counters, error, status, total;

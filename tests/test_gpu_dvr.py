@@ -338,6 +338,27 @@ def test_tile_order_rejections():
     assert order.cpu().tolist() == want.tolist()
 
 
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 1023, 1024, 1025, 4097, 32_400, 130_000, 262_144, 262_145, 300_000])
+def test_tile_order_is_the_stable_sort_by_cost_class(n):
+    """Frames of up to 2^18 tiles get their order from one launch, larger ones from a pass of the radix
+    sort: both are the stable sort of the tiles by cost class, costly first, whatever the workspace held
+    before (most tiles of a frame share a few classes: empty space, the volume's shell)."""
+    from raytracer_amd import _lib
+    l = _lib.lib()
+    rng = np.random.default_rng(n)
+    cost = np.where(rng.random(n) < 0.7, rng.integers(1, 4, n), rng.integers(0, 70_000, n)).astype(np.int32)
+    d_cost = torch.from_numpy(cost).to(DEV)
+    order = torch.full((n,), -1, dtype=torch.int32, device=DEV)
+    ws = torch.full((int(l.kk_dvr_tile_order_workspace_bytes(n)),), 0xAB, dtype=torch.uint8, device=DEV)
+    for _ in range(2):  # a second call finds what the first left in the workspace
+        _lib.check(l.kk_dvr_tile_order(d_cost.data_ptr(), n, order.data_ptr(), ws.data_ptr(), ws.numel(),
+                                       _lib.current_stream_ptr()), "kk_dvr_tile_order")
+        assert l.kk_dvr_tile_order_status(ws.data_ptr(), n, _lib.current_stream_ptr()) == 0
+        want = np.argsort(-_cost_class(cost.astype(np.int64)), kind="stable")
+        assert np.array_equal(order.cpu().numpy().astype(np.int64), want)
+        order.fill_(-1)
+
+
 def test_render_without_vdb_reports_and_returns(capsys):
     RayCaster(DEV).RenderDepthBoxVDB(FrameBuffer(8, 8, DEV))
     assert "vdb or tfTex are not set" in capsys.readouterr().err
