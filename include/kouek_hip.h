@@ -252,7 +252,10 @@ size_t kk_closest_hit_accel_workspace_bytes(uint32_t ray_num);
  * [1] triangles tested, [2] rays traced; diagnostics of the kernel's lane use: [3] passes of the wave
  * loop, [4] lanes that visited a record in them, [5] triangle phases, [6] lanes in them, [7] visits
  * that found no slot, [8] of those the ones that only the distance limit emptied, [9] used slots of
- * the visited records, [10] visits of records that hold leaves only. */
+ * the visited records, [10] visits of records that hold leaves only, [11] slots dropped unvisited
+ * (KK_TRACE_ENTRY_BOUND); wall clock in 10 ns ticks: [12] 2^62 - the earliest start of a wave, [13] 2^62 -
+ * the earliest moment a wave found every ray queue used up, [14] the latest exit of a wave, [15] the sum of
+ * the waves' lives. */
 int kk_closest_hit_accel(const void *d_accel, uint32_t face_num, uint32_t compacted_face_num,
                          const float *d_rays, uint32_t ray_num, float *d_t, float *d_bary,
                          uint32_t *d_prim, uint32_t flags, unsigned long long *d_counters,

@@ -864,6 +864,10 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(5, 5)))
     unsigned long long totNodes = 0, totTris = 0, totRays = 0;
     unsigned long long dbgIters = 0, dbgVisitLanes = 0, dbgTriRuns = 0, dbgTriLanes = 0, dbgEmpty = 0, dbgEmptyLimit = 0, dbgUsedSlots = 0, dbgLeafOnly = 0, dbgCulled = 0;
 
+    // COUNT: when the wave started, when it first found every queue used up, when it left (wall clock, 100 MHz)
+    const unsigned long long clkStart = COUNT ? wall_clock64() : 0ull;
+    unsigned long long clkEmpty = 0ull;
+
     auto restart = [&]() {
         best.t = FloatMax;
         best.bx = best.by = 0.f;
@@ -914,6 +918,8 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(5, 5)))
             if (base + want >= qLen || base + want < base) { // used up: the next refill asks the next queue
                 queue = queue + 1 == QUEUES ? 0u : queue + 1;
                 poolEmpty = ++queuesTried == QUEUES;
+                if (COUNT && poolEmpty)
+                    clkEmpty = wall_clock64();
             }
             if (!active) {
                 // idle lanes below this one (mbcnt: no lane mask kept in registers)
@@ -1091,6 +1097,14 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(5, 5)))
             atomicAdd(&counters[9], dbgUsedSlots);
             atomicAdd(&counters[10], dbgLeafOnly);
             atomicAdd(&counters[11], dbgCulled);
+            // earliest start, earliest "all queues used up", latest exit, and the sum of the waves' lives
+            constexpr unsigned long long TOP = 1ull << 62;
+            const unsigned long long clkExit = wall_clock64();
+            atomicMax(&counters[12], TOP - clkStart);
+            if (clkEmpty != 0ull)
+                atomicMax(&counters[13], TOP - clkEmpty);
+            atomicMax(&counters[14], clkExit);
+            atomicAdd(&counters[15], clkExit - clkStart);
         }
     }
 }

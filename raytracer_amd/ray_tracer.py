@@ -79,7 +79,13 @@ def closest_hit(lbvh: LBVH, rays, count: bool = False, out=None, layout: str = "
                                "wave_passes": int(c[3]), "visit_lanes": int(c[4]), "tri_phases": int(c[5]),
                                "tri_lanes": int(c[6]), "empty_visits": int(c[7]),
                                "empty_visits_by_limit": int(c[8]), "used_slots_visited": int(c[9]),
-                               "leaf_only_visits": int(c[10]), "slots_dropped_unvisited": int(c[11])}
+                               "leaf_only_visits": int(c[10]), "slots_dropped_unvisited": int(c[11]),
+                               # wall clock (100 MHz ticks -> us): the launch from its first wave's start to
+                               # its last wave's exit, how long before that exit the first wave found every
+                               # queue used up, and the mean life of a wave
+                               "launch_us": (int(c[14]) - ((1 << 62) - int(c[12]))) / 100.0,
+                               "tail_us": (int(c[14]) - ((1 << 62) - int(c[13]))) / 100.0 if c[13] else 0.0,
+                               "wave_life_sum_us": int(c[15]) / 100.0}
     return t, bary, prim
 
 

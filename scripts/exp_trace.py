@@ -30,7 +30,13 @@ hdr = bvh.trace_accel()[:64].view(torch.int32).cpu().numpy()
 print("wide nodes:", int(hdr[10]), "of", int(hdr[7]), "binary nodes")
 got = closest_hit(bvh, rays, count=True)
 c = got[3]
-print({k: round(v / R, 2) for k, v in c.items()})
+print({k: round(v / R, 2) for k, v in c.items() if not k.endswith("_us")})
+for _ in range(2):
+    c2 = closest_hit(bvh, rays, count=True)[3]
+    print(f"counting launch again: {c2['launch_us']:.0f} us, queues used up {c2['tail_us']:.0f} us before the last exit, "
+          f"mean life of a wave {c2['wave_life_sum_us'] / 5120:.0f} us")
+print(f"counting launch: {c['launch_us']:.0f} us from first start to last exit; the first wave found the queues used up "
+      f"{c['tail_us']:.0f} us before the last exit; mean life of a wave {c['wave_life_sum_us'] / 5120:.0f} us (5120 waves)")
 it = max(c["wave_passes"], 1)
 print(f"visit lanes/pass {c['visit_lanes'] / it:.1f}, tri phases/pass {c['tri_phases'] / it:.3f}, "
       f"lanes/tri phase {c['tri_lanes'] / max(c['tri_phases'], 1):.1f}")
