@@ -7,6 +7,8 @@ import os, sys, time
 HERE = os.path.dirname(os.path.abspath(__file__))
 exec(open(os.path.join(HERE, "exp_dvr_inflight.py")).read().split("for k in (1, 2, 3):")[0])
 from raytracer_amd import _lib
+if os.environ.get("KK_LIB"):  # another build of the library, for A/B runs on one box
+    _lib.LIB_PATH = os.path.abspath(os.environ["KK_LIB"])
 L = _lib.lib()
 fb = FrameBuffer(W, H, dev)
 n = int(L.kk_dvr_tile_count(W, H))
