@@ -36,4 +36,23 @@ for it in range(rounds):
         bad += 1
         print("build", it, "differs", flush=True)
 print(f"{rounds} builds of {N} triangles, {bad} bad")
+# Two different soups in turn through the same buffers: a build that read anything the build before left
+# behind (in a cache of another XCD, in a counter that was not cleared) would not give the bytes of a first build.
+pos_b, _ = syn.triangle_soup(N, seed=12345)
+d_a = bvh.d_positions.clone()
+d_b = torch.from_numpy(pos_b).to(dev).reshape(bvh.d_positions.shape)
+bvh.d_positions.copy_(d_b)
+bvh.rebuild()
+torch.cuda.synchronize()
+want_b = digest()
+assert want_b != want
+for it in range(rounds // 2):
+    for src, w in ((d_a, want), (d_b, want_b)):
+        bvh.d_positions.copy_(src)
+        bvh.rebuild()
+        torch.cuda.synchronize()
+        if digest() != w:
+            bad += 1
+            print("alternating build", it, "differs", flush=True)
+print(f"{rounds // 2} x 2 alternating builds, {bad} bad")
 sys.exit(1 if bad else 0)
