@@ -154,24 +154,19 @@ template <> struct Norm<uint16_t> {
 
 // Trilinear sample of one brick. `sp` is the sample position in global atlas voxel coordinates,
 // `origin` the brick's first voxel in those coordinates.
+// `originLin` = the brick's first voxel as an offset in a cube of edge A, (z A + y) A + x.
 template <typename T>
-KK_D float sampleBrick(const T *__restrict__ brick, int A, i3 origin, f3 sp, const Norm<T> &norm) {
+KK_D float sampleBrick(const T *__restrict__ brick, int A, int originLin, f3 sp, const Norm<T> &norm) {
     const f3 b = sp - .5f;
     const f3 fl = vfloor(b);
     const float ax = b.x - fl.x, ay = b.y - fl.y, az = b.z - fl.z;
-    int i = static_cast<int>(fl.x) - origin.x;
-    int j = static_cast<int>(fl.y) - origin.y;
-    int k = static_cast<int>(fl.z) - origin.z;
-    // A ray inside a brick's [0, dims0) box with the apron around it never leaves [0, A-2]; the clamp
-    // only guards the address against non-finite coordinates.
-    i = max(0, min(i, A - 2));
-    j = max(0, min(j, A - 2));
-    k = max(0, min(k, A - 2));
-    // offsets inside a brick fit 32 bits
-    const T *p = brick + (static_cast<uint32_t>(k) * static_cast<uint32_t>(A) + static_cast<uint32_t>(j)) *
-                             static_cast<uint32_t>(A) +
-                 static_cast<uint32_t>(i);
+    // The first of the eight taps, as one offset inside the brick (offsets inside a brick fit 32 bits). A
+    // ray inside a brick's [0, dims0) box with the apron around it never leaves [0, A-2] along any axis;
+    // the clamp of the offset only guards the address against non-finite coordinates.
     const int sy = A, sz = A * A;
+    int lin = (static_cast<int>(fl.z) * A + static_cast<int>(fl.y)) * A + static_cast<int>(fl.x) - originLin;
+    lin = max(0, min(lin, A * sz - 1 - (sz + sy + 1)));
+    const T *p = brick + static_cast<uint32_t>(lin);
     const float v000 = norm(p[0]), v001 = norm(p[1]);
     const float v010 = norm(p[sy]), v011 = norm(p[sy + 1]);
     const float v100 = norm(p[sz]), v101 = norm(p[sz + 1]);
@@ -467,6 +462,7 @@ __global__ __launch_bounds__(THREADS) void dvr_kernel(const kk_vdb_device_data v
                                                         static_cast<float>(origin.y + p.apron_dep_wid),
                                                         static_cast<float>(origin.z + p.apron_dep_wid)};
                         const T *__restrict__ brick = atlas + brickVox * ch;
+                        const int originLin = (origin.z * A + origin.y) * A + origin.x;
                         bool skipped = false;
                         if (useDepthBox) {
                             // depthSkip, :139-162
@@ -499,13 +495,12 @@ __global__ __launch_bounds__(THREADS) void dvr_kernel(const kk_vdb_device_data v
                             }
                         }
                         if (!skipped) {
-                            // one test per pass: the conjunction is evaluated whole, not term by term
-                            while ((param.tCurr < param.tExit) & !(posInBrick.x < 0.f) &
-                                   !(posInBrick.x >= dims0f) & !(posInBrick.y < 0.f) &
-                                   !(posInBrick.y >= dims0f) & !(posInBrick.z < 0.f) &
-                                   !(posInBrick.z >= dims0f)) {
+                            // One sample: value, colour, compositing, and the step to the next one (taken whether
+                            // or not the ray ends here: a ray that ends has no use for its position any more,
+                            // and the others need no select).
+                            auto takeSample = [&]() {
                                 f3 samplePos = atlasBrickMinVoxPos + posInBrick;
-                                const float scalar = sampleBrick<T>(brick, A, origin, samplePos, norm);
+                                const float scalar = sampleBrick<T>(brick, A, originLin, samplePos, norm);
                                 const f4 tfCol = tfLookup(s_tf, scalar);
                                 f3 tfColRGB = {tfCol.x, tfCol.y, tfCol.z};
                                 if (COUNT)
@@ -513,19 +508,19 @@ __global__ __launch_bounds__(THREADS) void dvr_kernel(const kk_vdb_device_data v
                                 if (SHADING) {
                                     f3 N;
                                     samplePos.x += .5f;
-                                    float v0 = sampleBrick<T>(brick, A, origin, samplePos, norm);
+                                    float v0 = sampleBrick<T>(brick, A, originLin, samplePos, norm);
                                     samplePos.x -= 1.f;
-                                    float v1 = sampleBrick<T>(brick, A, origin, samplePos, norm);
+                                    float v1 = sampleBrick<T>(brick, A, originLin, samplePos, norm);
                                     N.x = v1 - v0;
                                     samplePos.y += .5f;
-                                    v0 = sampleBrick<T>(brick, A, origin, samplePos, norm);
+                                    v0 = sampleBrick<T>(brick, A, originLin, samplePos, norm);
                                     samplePos.y -= 1.f;
-                                    v1 = sampleBrick<T>(brick, A, origin, samplePos, norm);
+                                    v1 = sampleBrick<T>(brick, A, originLin, samplePos, norm);
                                     N.y = v1 - v0;
                                     samplePos.z += .5f;
-                                    v0 = sampleBrick<T>(brick, A, origin, samplePos, norm);
+                                    v0 = sampleBrick<T>(brick, A, originLin, samplePos, norm);
                                     samplePos.z -= 1.f;
-                                    v1 = sampleBrick<T>(brick, A, origin, samplePos, norm);
+                                    v1 = sampleBrick<T>(brick, A, originLin, samplePos, norm);
                                     N.z = v1 - v0;
                                     N = normalize(N);
                                     if (dot(eyeRay.dir, N) > 0.f)
@@ -545,13 +540,31 @@ __global__ __launch_bounds__(THREADS) void dvr_kernel(const kk_vdb_device_data v
                                 }
                                 rgb = rgb + (1.f - a) * tfCol.w * tfColRGB;
                                 a = a + (1.f - a) * tfCol.w;
-                                if (a >= rp.max_alpha) {
-                                    keepGoing = false;
-                                    break;
-                                }
                                 param.tCurr += step;
                                 posInBrick = posInBrick + dltPos;
-                            }
+                            };
+                            // One test per pass: the conjunction is evaluated whole, not term by term, and the six
+                            // bounds as two: no coordinate below 0 = the smallest is not, none at or above the edge
+                            // = the largest is not (a NaN coordinate fails no comparison either way: the smallest
+                            // and the largest of three skip it, and are NaN themselves when all three are).
+                            auto inBrick = [&]() {
+                                return (param.tCurr < param.tExit) &
+                                       !(__builtin_fminf(__builtin_fminf(posInBrick.x, posInBrick.y), posInBrick.z) < 0.f) &
+                                       !(__builtin_fmaxf(__builtin_fmaxf(posInBrick.x, posInBrick.y), posInBrick.z) >= dims0f);
+                            };
+                            // The reference ends a ray after the sample that takes its opacity to the limit. A ray
+                            // that gets here is below a positive limit, so testing before every sample is the same
+                            // loop with one way out and no flag to carry; a limit of zero or less (one sample per
+                            // ray) keeps the reference's form.
+                            if (rp.max_alpha > 0.f) {
+                                while (inBrick() & !(a >= rp.max_alpha))
+                                    takeSample();
+                                keepGoing = !(a >= rp.max_alpha);
+                            } else
+                                while (inBrick() & keepGoing) {
+                                    takeSample();
+                                    keepGoing = !(a >= rp.max_alpha);
+                                }
                         }
                     }
                     if (!keepGoing)

@@ -5,10 +5,11 @@ The set-up is the first part of exp_dvr_inflight.py."""
 import ctypes as C
 import os, sys, time
 HERE = os.path.dirname(os.path.abspath(__file__))
-exec(open(os.path.join(HERE, "exp_dvr_inflight.py")).read().split("for k in (1, 2, 3):")[0])
+sys.path.insert(0, os.path.dirname(HERE))
 from raytracer_amd import _lib
-if os.environ.get("KK_LIB"):  # another build of the library, for A/B runs on one box
+if os.environ.get("KK_LIB"):  # another build of the library, for A/B runs on one box (before anything loads it)
     _lib.LIB_PATH = os.path.abspath(os.environ["KK_LIB"])
+exec(open(os.path.join(HERE, "exp_dvr_inflight.py")).read().split("for k in (1, 2, 3):")[0])
 L = _lib.lib()
 fb = FrameBuffer(W, H, dev)
 n = int(L.kk_dvr_tile_count(W, H))
