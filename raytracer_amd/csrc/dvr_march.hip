@@ -171,13 +171,15 @@ KK_D float sampleBrick(const T *__restrict__ brick, int A, int originLin, f3 sp,
     const float v010 = norm(p[sy]), v011 = norm(p[sy + 1]);
     const float v100 = norm(p[sz]), v101 = norm(p[sz + 1]);
     const float v110 = norm(p[sz + sy]), v111 = norm(p[sz + sy + 1]);
-    const float c00 = (1.f - ax) * v000 + ax * v001;
-    const float c01 = (1.f - ax) * v010 + ax * v011;
-    const float c10 = (1.f - ax) * v100 + ax * v101;
-    const float c11 = (1.f - ax) * v110 + ax * v111;
-    const float c0 = (1.f - ay) * c00 + ay * c01;
-    const float c1 = (1.f - ay) * c10 + ay * c11;
-    return (1.f - az) * c0 + az * c1;
+    // The same products and sums as ((1-ax) v0 + ax v1 along x, then y, then z), two at a time: the four
+    // mixes along x as two register pairs (one per y), the two along y as one.
+    typedef float pair __attribute__((ext_vector_type(2)));
+    const pair wx0 = {1.f - ax, 1.f - ax}, wx1 = {ax, ax}, wy0 = {1.f - ay, 1.f - ay}, wy1 = {ay, ay};
+    const pair lo = wx0 * pair{v000, v100} + wx1 * pair{v001, v101}; // c00, c10
+    const pair hi = wx0 * pair{v010, v110} + wx1 * pair{v011, v111}; // c01, c11
+    const pair c = wy0 * lo + wy1 * hi;                               // c0, c1
+    const pair z = pair{1.f - az, az} * c;
+    return z.x + z.y;
 }
 
 // The table in LDS is padded: entry 0 and entries 257, 258 are zero, entry 1 + i is tf[i], so the two
@@ -187,6 +189,25 @@ KK_D void tfStage(float4 *s_tf, const float *__restrict__ tf, int tid) { // 256 
     s_tf[1 + tid] = reinterpret_cast<const float4 *>(tf)[tid];
     if (tid < 3)
         s_tf[tid == 0 ? 0 : 256 + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+// The same lookup with the colour as two register pairs (red, green) and (blue, opacity), which is how the
+// two 16-byte reads land: the mix of the two taps is then six packed operations and nothing is moved.
+typedef float v2f __attribute__((ext_vector_type(2)));
+struct TfPairs {
+    v2f rg, ba;
+};
+KK_D TfPairs tfLookupPairs(const float4 *__restrict__ s_tf, float u) {
+    const float x = u * 256.f - .5f;
+    const float fl = floorf(x);
+    const float a = x - fl;
+    int i = static_cast<int>(fl);
+    i = i < -1 ? -1 : (i > 256 ? 256 : i); // taps outside [0, 255] read zeros
+    const float4 t0 = s_tf[i + 1], t1 = s_tf[i + 2];
+    const v2f w0 = {1.f - a, 1.f - a}, w1 = {a, a};
+    TfPairs r;
+    r.rg = v2f{t0.x, t0.y} * w0 + v2f{t1.x, t1.y} * w1;
+    r.ba = v2f{t0.z, t0.w} * w0 + v2f{t1.z, t1.w} * w1;
+    return r;
 }
 KK_D f4 tfLookup(const float4 *__restrict__ s_tf, float u) {
     const float x = u * 256.f - .5f;
@@ -501,7 +522,8 @@ __global__ __launch_bounds__(THREADS) void dvr_kernel(const kk_vdb_device_data v
                             auto takeSample = [&]() {
                                 f3 samplePos = atlasBrickMinVoxPos + posInBrick;
                                 const float scalar = sampleBrick<T>(brick, A, originLin, samplePos, norm);
-                                const f4 tfCol = tfLookup(s_tf, scalar);
+                                const TfPairs tfPairs = tfLookupPairs(s_tf, scalar);
+                                const f4 tfCol = {tfPairs.rg.x, tfPairs.rg.y, tfPairs.ba.x, tfPairs.ba.y};
                                 f3 tfColRGB = {tfCol.x, tfCol.y, tfCol.z};
                                 if (COUNT)
                                     ++nSamples;
@@ -538,8 +560,11 @@ __global__ __launch_bounds__(THREADS) void dvr_kernel(const kk_vdb_device_data v
                                                 ambient.y + diffuse.y + specular.y,
                                                 ambient.z + diffuse.z + specular.z};
                                 }
-                                rgb = rgb + (1.f - a) * tfCol.w * tfColRGB;
-                                a = a + (1.f - a) * tfCol.w;
+                                // rgb += ((1 - a) tfCol.w) tfColRGB, a += (1 - a) tfCol.w: red and green as a pair
+                                const float wgt = (1.f - a) * tfCol.w;
+                                const v2f rg = v2f{rgb.x, rgb.y} + v2f{wgt, wgt} * v2f{tfColRGB.x, tfColRGB.y};
+                                rgb = {rg.x, rg.y, rgb.z + wgt * tfColRGB.z};
+                                a = a + wgt;
                                 param.tCurr += step;
                                 posInBrick = posInBrick + dltPos;
                             };
@@ -559,6 +584,9 @@ __global__ __launch_bounds__(THREADS) void dvr_kernel(const kk_vdb_device_data v
                             if (rp.max_alpha > 0.f) {
                                 while (inBrick() & !(a >= rp.max_alpha))
                                     takeSample();
+                                // (asked again of a value the compiler cannot trace back into the loop: it would
+                                // otherwise carry the loop's own comparison out of it, three mask operations a sample)
+                                asm volatile("" : "+v"(a));
                                 keepGoing = !(a >= rp.max_alpha);
                             } else
                                 while (inBrick() & keepGoing) {
