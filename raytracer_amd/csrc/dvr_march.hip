@@ -57,11 +57,16 @@ struct HDDA3D {
         mask.z = static_cast<int>((tSide.z < tSide.x) & (tSide.z <= tSide.y));
         tNext = mask.x ? tSide.x : mask.y ? tSide.y : mask.z ? tSide.z : INFINITY;
     }
+    // dda.h:74-81 also sets the side distance of an axis with an infinite step to infinity here. It is
+    // that already: such an axis has direction 0 and sign 0, so Prepare gave it (0 + 0.5) * inf + tCurr, its
+    // mask is never set and nothing is ever added to it. (A denormal direction component - sign +-1, step
+    // inf - can give 0 * inf = NaN there; then no axis is ever the nearest, tNext is infinite at once and
+    // the walk ends with or without the assignment.)
     KK_D void Step() {
         tCurr = tNext;
-        tSide.x = isInf(tDlt.x) ? INFINITY : mask.x ? tSide.x + tDlt.x : tSide.x;
-        tSide.y = isInf(tDlt.y) ? INFINITY : mask.y ? tSide.y + tDlt.y : tSide.y;
-        tSide.z = isInf(tDlt.z) ? INFINITY : mask.z ? tSide.z + tDlt.z : tSide.z;
+        tSide.x = mask.x ? tSide.x + tDlt.x : tSide.x;
+        tSide.y = mask.y ? tSide.y + tDlt.y : tSide.y;
+        tSide.z = mask.z ? tSide.z + tDlt.z : tSide.z;
         chPos.x += mask.x * sign.x;
         chPos.y += mask.y * sign.y;
         chPos.z += mask.z * sign.z;
@@ -123,9 +128,10 @@ struct DepthDDA2D {
         mask.z = static_cast<int>((tSide.z < tSide.x) & (tSide.z <= tSide.y));
         t = mask.x ? tSide.x : mask.y ? tSide.y : mask.z ? tSide.z : INFINITY;
         dep = tDlt2Dep * (t - tStart);
-        tSide.x = isInf(tDlt.x) ? INFINITY : mask.x ? tSide.x + tDlt.x : tSide.x;
-        tSide.y = isInf(tDlt.y) ? INFINITY : mask.y ? tSide.y + tDlt.y : tSide.y;
-        tSide.z = isInf(tDlt.z) ? INFINITY : mask.z ? tSide.z + tDlt.z : tSide.z;
+        // (as in HDDA3D::Step: an axis with an infinite step, or the face's own axis, is at infinity already)
+        tSide.x = mask.x ? tSide.x + tDlt.x : tSide.x;
+        tSide.y = mask.y ? tSide.y + tDlt.y : tSide.y;
+        tSide.z = mask.z ? tSide.z + tDlt.z : tSide.z;
         posInBrick.x += mask.x * sign.x;
         posInBrick.y += mask.y * sign.y;
         posInBrick.z += mask.z * sign.z;
@@ -413,30 +419,25 @@ __global__ __launch_bounds__(THREADS) void dvr_kernel(const kk_vdb_device_data v
                     uint32_t cell = cellOf(h.chPos);
                     bool inGrid = cell != UndefRltIdx;
                     uint32_t ch = children[inGrid ? cell : 0u];
-                    uint32_t chAhead = UndefRltIdx;
-                    // one cell: true when the run over empty cells ends here
-                    auto visit = [&](uint32_t &chHere, uint32_t &chNext) -> bool {
-                        if (!inGrid)
-                            return true;
+                    // One cell per pass; the run over empty cells ends at a child, at the grid's end or at
+                    // the node's exit. The loop has one way out: `walking` says whether to go on.
+                    bool walking = inGrid;
+                    while (walking) {
                         h.Next();
                         const uint32_t nextCell = cellOf(i3{h.chPos.x + h.mask.x * h.sign.x,
                                                             h.chPos.y + h.mask.y * h.sign.y,
                                                             h.chPos.z + h.mask.z * h.sign.z});
-                        chNext = children[nextCell != UndefRltIdx ? nextCell : 0u];
-                        if (chHere != UndefRltIdx)
-                            return true;
-                        h.Step();
-                        if (h.tCurr >= tExitLev || --budget < 0)
-                            return true; // the node's exit comes before the grid's end
-                        inGrid = nextCell != UndefRltIdx;
-                        return false;
-                    };
-                    for (;;) {
-                        if (visit(ch, chAhead))
-                            break;
-                        if (visit(chAhead, ch)) {
-                            ch = chAhead;
-                            break;
+                        const uint32_t chNext = children[nextCell != UndefRltIdx ? nextCell : 0u];
+                        walking = ch == UndefRltIdx;
+                        if (walking) {
+                            h.Step();
+                            // the node's exit comes before the grid's end: the cell stays the one it was then
+                            const bool out = h.tCurr >= tExitLev || --budget < 0;
+                            if (!out) {
+                                inGrid = nextCell != UndefRltIdx;
+                                ch = chNext;
+                            }
+                            walking = !out & inGrid;
                         }
                     }
                     if (!inGrid || budget < 0)
@@ -597,6 +598,7 @@ __global__ __launch_bounds__(THREADS) void dvr_kernel(const kk_vdb_device_data v
                     }
                     if (!keepGoing)
                         break;
+                    h.Next(); // (the masks of the walk's last Next, made again here instead of kept across the leaf)
                     h.Step();
                     ascend();
                 }
