@@ -7,7 +7,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libkouek_hip.so")
+# (KK_LIB_PATH: another build of the library, for comparing two builds on one machine)
+LIB_PATH = os.environ.get("KK_LIB_PATH") or os.path.join(_HERE, "lib", "libkouek_hip.so")
 
 
 class KoukeError(RuntimeError):
