@@ -161,22 +161,46 @@ template <> struct Norm<uint16_t> {
 // Trilinear sample of one brick. `sp` is the sample position in global atlas voxel coordinates,
 // `origin` the brick's first voxel in those coordinates.
 // `originLin` = the brick's first voxel as an offset in a cube of edge A, (z A + y) A + x.
-template <typename T>
-KK_D float sampleBrick(const T *__restrict__ brick, int A, int originLin, f3 sp, const Norm<T> &norm) {
+// FLOATLIN: the launch has checked that the offset of any voxel of the atlas in a cube of edge A, and the
+// atlas' size in bytes, are below 2^24 and 2^32. The offset of the first tap is then made in floating point
+// (whole numbers below 2^24: the two multiply-adds are exact, one conversion instead of three and no
+// integer multiplications), and `brick` is the atlas itself with the brick's first voxel in `brickOff`, so
+// that the taps are loads from one base pointer for the whole wave plus a 32-bit offset per lane.
+#ifndef KK_DVR_FLOAT_OFFSETS
+#define KK_DVR_FLOAT_OFFSETS 1 // 0: the integer form everywhere (for comparisons)
+#endif
+template <typename T> struct Taps {
+    T v000, v001, v010, v011, v100, v101, v110, v111; // v<z><y><x>
+    float ax, ay, az;                                  // where the sample lies between them
+};
+template <typename T, bool FLOATLIN = false>
+KK_D Taps<T> fetchTaps(const T *__restrict__ brick, int A, int originLin, f3 sp, uint32_t brickOff = 0u) {
     const f3 b = sp - .5f;
     const f3 fl = vfloor(b);
-    const float ax = b.x - fl.x, ay = b.y - fl.y, az = b.z - fl.z;
     // The first of the eight taps, as one offset inside the brick (offsets inside a brick fit 32 bits). A
     // ray inside a brick's [0, dims0) box with the apron around it never leaves [0, A-2] along any axis;
     // the clamp of the offset only guards the address against non-finite coordinates.
     const int sy = A, sz = A * A;
-    int lin = (static_cast<int>(fl.z) * A + static_cast<int>(fl.y)) * A + static_cast<int>(fl.x) - originLin;
+    int lin;
+    if (FLOATLIN) {
+        const float Af = static_cast<float>(A);
+        lin = static_cast<int>(__builtin_fmaf(__builtin_fmaf(fl.z, Af, fl.y), Af, fl.x)) - originLin;
+    } else
+        lin = (static_cast<int>(fl.z) * A + static_cast<int>(fl.y)) * A + static_cast<int>(fl.x) - originLin;
     lin = max(0, min(lin, A * sz - 1 - (sz + sy + 1)));
-    const T *p = brick + static_cast<uint32_t>(lin);
-    const float v000 = norm(p[0]), v001 = norm(p[1]);
-    const float v010 = norm(p[sy]), v011 = norm(p[sy + 1]);
-    const float v100 = norm(p[sz]), v101 = norm(p[sz + 1]);
-    const float v110 = norm(p[sz + sy]), v111 = norm(p[sz + sy + 1]);
+    const T *p = brick + (static_cast<uint32_t>(lin) + brickOff);
+    Taps<T> t;
+    t.v000 = p[0], t.v001 = p[1];
+    t.v010 = p[sy], t.v011 = p[sy + 1];
+    t.v100 = p[sz], t.v101 = p[sz + 1];
+    t.v110 = p[sz + sy], t.v111 = p[sz + sy + 1];
+    t.ax = b.x - fl.x, t.ay = b.y - fl.y, t.az = b.z - fl.z;
+    return t;
+}
+template <typename T> KK_D float mixTaps(const Taps<T> &t, const Norm<T> &norm) {
+    const float v000 = norm(t.v000), v001 = norm(t.v001), v010 = norm(t.v010), v011 = norm(t.v011);
+    const float v100 = norm(t.v100), v101 = norm(t.v101), v110 = norm(t.v110), v111 = norm(t.v111);
+    const float ax = t.ax, ay = t.ay, az = t.az;
     // The same products and sums as ((1-ax) v0 + ax v1 along x, then y, then z), two at a time: the four
     // mixes along x as two register pairs (one per y), the two along y as one.
     typedef float pair __attribute__((ext_vector_type(2)));
@@ -186,6 +210,11 @@ KK_D float sampleBrick(const T *__restrict__ brick, int A, int originLin, f3 sp,
     const pair c = wy0 * lo + wy1 * hi;                               // c0, c1
     const pair z = pair{1.f - az, az} * c;
     return z.x + z.y;
+}
+template <typename T, bool FLOATLIN = false>
+KK_D float sampleBrick(const T *__restrict__ brick, int A, int originLin, f3 sp, const Norm<T> &norm,
+                       uint32_t brickOff = 0u) {
+    return mixTaps<T>(fetchTaps<T, FLOATLIN>(brick, A, originLin, sp, brickOff), norm);
 }
 
 // The table in LDS is padded: entry 0 and entries 257, 258 are zero, entry 1 + i is tf[i], so the two
@@ -282,6 +311,7 @@ __global__ __launch_bounds__(THREADS) void dvr_kernel(const kk_vdb_device_data v
         const uint32_t *__restrict__ childPools = vdb.child_pools;
         const T *__restrict__ atlas = static_cast<const T *>(vdb.atlas);
         const int A = AFIX ? AFIX : p.vox_per_atlas_brick;
+        constexpr bool FLOAT_OFFSETS = KK_DVR_FLOAT_OFFSETS && AFIX != 0;
         const size_t brickVox = static_cast<size_t>(A) * A * A;
         const bool useDepthBox = p.apron_dep_wid != p.apron_wid;
         const f3 voxPerVol = {p.vox_per_vol[0], p.vox_per_vol[1], p.vox_per_vol[2]};
@@ -485,6 +515,9 @@ __global__ __launch_bounds__(THREADS) void dvr_kernel(const kk_vdb_device_data v
                                                         static_cast<float>(origin.z + p.apron_dep_wid)};
                         const T *__restrict__ brick = atlas + brickVox * ch;
                         const int originLin = (origin.z * A + origin.y) * A + origin.x;
+                        // the samples' taps: from the atlas plus a 32-bit offset where the launch allows it
+                        const T *__restrict__ sampleBase = FLOAT_OFFSETS ? atlas : brick;
+                        const uint32_t sampleOff = FLOAT_OFFSETS ? static_cast<uint32_t>(brickVox) * ch : 0u;
                         bool skipped = false;
                         if (useDepthBox) {
                             // depthSkip, :139-162
@@ -522,7 +555,7 @@ __global__ __launch_bounds__(THREADS) void dvr_kernel(const kk_vdb_device_data v
                             // and the others need no select).
                             auto takeSample = [&]() {
                                 f3 samplePos = atlasBrickMinVoxPos + posInBrick;
-                                const float scalar = sampleBrick<T>(brick, A, originLin, samplePos, norm);
+                                const float scalar = sampleBrick<T, FLOAT_OFFSETS>(sampleBase, A, originLin, samplePos, norm, sampleOff);
                                 const TfPairs tfPairs = tfLookupPairs(s_tf, scalar);
                                 const f4 tfCol = {tfPairs.rg.x, tfPairs.rg.y, tfPairs.ba.x, tfPairs.ba.y};
                                 f3 tfColRGB = {tfCol.x, tfCol.y, tfCol.z};
@@ -531,19 +564,19 @@ __global__ __launch_bounds__(THREADS) void dvr_kernel(const kk_vdb_device_data v
                                 if (SHADING) {
                                     f3 N;
                                     samplePos.x += .5f;
-                                    float v0 = sampleBrick<T>(brick, A, originLin, samplePos, norm);
+                                    float v0 = sampleBrick<T, FLOAT_OFFSETS>(sampleBase, A, originLin, samplePos, norm, sampleOff);
                                     samplePos.x -= 1.f;
-                                    float v1 = sampleBrick<T>(brick, A, originLin, samplePos, norm);
+                                    float v1 = sampleBrick<T, FLOAT_OFFSETS>(sampleBase, A, originLin, samplePos, norm, sampleOff);
                                     N.x = v1 - v0;
                                     samplePos.y += .5f;
-                                    v0 = sampleBrick<T>(brick, A, originLin, samplePos, norm);
+                                    v0 = sampleBrick<T, FLOAT_OFFSETS>(sampleBase, A, originLin, samplePos, norm, sampleOff);
                                     samplePos.y -= 1.f;
-                                    v1 = sampleBrick<T>(brick, A, originLin, samplePos, norm);
+                                    v1 = sampleBrick<T, FLOAT_OFFSETS>(sampleBase, A, originLin, samplePos, norm, sampleOff);
                                     N.y = v1 - v0;
                                     samplePos.z += .5f;
-                                    v0 = sampleBrick<T>(brick, A, originLin, samplePos, norm);
+                                    v0 = sampleBrick<T, FLOAT_OFFSETS>(sampleBase, A, originLin, samplePos, norm, sampleOff);
                                     samplePos.z -= 1.f;
-                                    v1 = sampleBrick<T>(brick, A, originLin, samplePos, norm);
+                                    v1 = sampleBrick<T, FLOAT_OFFSETS>(sampleBase, A, originLin, samplePos, norm, sampleOff);
                                     N.z = v1 - v0;
                                     N = normalize(N);
                                     if (dot(eyeRay.dir, N) > 0.f)
@@ -582,7 +615,45 @@ __global__ __launch_bounds__(THREADS) void dvr_kernel(const kk_vdb_device_data v
                             // that gets here is below a positive limit, so testing before every sample is the same
                             // loop with one way out and no flag to carry; a limit of zero or less (one sample per
                             // ray) keeps the reference's form.
-                            if (rp.max_alpha > 0.f) {
+                            if (!SHADING && !COUNT && rp.max_alpha > 0.f) {
+                                // The same loop with the taps of the next sample asked for before the present
+                                // one is mixed and composited (its position does not depend on the colour): the
+                                // loads' way through the caches runs beside the table lookups and the
+                                // arithmetic of the sample before. A ray that ends has asked for eight bytes it
+                                // does not use (the offset is clamped into the brick whatever the position).
+                                auto fetch = [&]() {
+                                    return fetchTaps<T, FLOAT_OFFSETS>(sampleBase, A, originLin,
+                                                                       atlasBrickMinVoxPos + posInBrick, sampleOff);
+                                };
+                                auto composite = [&](const Taps<T> &t) {
+                                    const TfPairs tfc = tfLookupPairs(s_tf, mixTaps<T>(t, norm));
+                                    const float wgt = (1.f - a) * tfc.ba.y;
+                                    const v2f rg = v2f{rgb.x, rgb.y} + v2f{wgt, wgt} * tfc.rg;
+                                    rgb = {rg.x, rg.y, rgb.z + wgt * tfc.ba.x};
+                                    a = a + wgt;
+                                };
+                                if (inBrick() & !(a >= rp.max_alpha)) {
+                                    Taps<T> even = fetch(), odd;
+                                    while (true) {
+                                        param.tCurr += step;
+                                        posInBrick = posInBrick + dltPos;
+                                        bool more = inBrick();
+                                        odd = fetch();
+                                        composite(even);
+                                        if (!(more & !(a >= rp.max_alpha)))
+                                            break;
+                                        param.tCurr += step;
+                                        posInBrick = posInBrick + dltPos;
+                                        more = inBrick();
+                                        even = fetch();
+                                        composite(odd);
+                                        if (!(more & !(a >= rp.max_alpha)))
+                                            break;
+                                    }
+                                }
+                                asm volatile("" : "+v"(a));
+                                keepGoing = !(a >= rp.max_alpha);
+                            } else if (rp.max_alpha > 0.f) {
                                 while (inBrick() & !(a >= rp.max_alpha))
                                     takeSample();
                                 // (asked again of a value the compiler cannot trace back into the loop: it would
@@ -1087,7 +1158,14 @@ int launch(const kk_vdb_device_data *h_vdb, const float *d_tf, const kk_dvr_para
         *h_vdb, d_tf, *h_params, *h_frame, d_rgba, width, height, y0, y1, stripeFirst, stripeStride, compact, \
         d_counters, d_tile_cost, d_tile_order)
     const bool shading = h_params->use_shading != 0;
-    const bool edge36 = h_vdb->vdb_param.vox_per_atlas_brick == 36;
+    // The variant for the 36-voxel atlas brick makes a sample's offsets in floating point and in 32 bits: every
+    // voxel's offset in a cube of edge 36 must stay below 2^24 and the atlas below 4 GiB.
+    const kk_vdb_param &vp = h_vdb->vdb_param;
+    const uint64_t cubeEnd = (static_cast<uint64_t>(vp.atlas_brick_per_vdb[2] > 0 ? vp.atlas_brick_per_vdb[2] : 0) * 36u * 36u +
+                              static_cast<uint64_t>(vp.atlas_brick_per_vdb[1] > 0 ? vp.atlas_brick_per_vdb[1] : 0) * 36u) * 36u +
+                             static_cast<uint64_t>(vp.atlas_brick_per_vdb[0] > 0 ? vp.atlas_brick_per_vdb[0] : 0) * 36u;
+    const bool edge36 = vp.vox_per_atlas_brick == 36 && cubeEnd < (1ull << 24) &&
+                        h_vdb->leaf_num * (36ull * 36ull * 36ull) * sizeof(T) < (1ull << 32);
     if (d_counters) {
         if (shading)
             KK_LAUNCH_DVR(true, true, 0);
