@@ -196,6 +196,28 @@ def test_render_with_shading(oracle):
     _check_images(got, want)
 
 
+@pytest.mark.parametrize("dtype,depth", [(np.uint8, True), (np.uint8, False), (np.uint16, True)])
+def test_kernel_for_36_voxel_bricks_equals_the_general_one(oracle, dtype, depth):
+    """32-voxel leaves with the depth-box apron make 36-voxel atlas bricks, which have a kernel of their own
+    (offsets of a sample's voxels made in floating point, taps of the next sample asked for before the
+    present one is composited). A frame rendered with work counters goes through the general kernel, which
+    is the one compared with the checker here; without counters it must be the same bytes."""
+    vol = blob_volume((70, 90, 100), seed=11, dtype=dtype)
+    top = 255 if dtype == np.uint8 else 65535
+    rng = np.array([[0, int(0.16 * top)]], dtype)
+    vdb, ref = _build_both(oracle, vol, (5, 2, 2), rng, depth)
+    assert vdb.plan.param.vox_per_atlas_brick == (36 if depth else 34)
+    for orbit, max_alpha in ((20, 0.9), (200, 0.5)):
+        got, want, ns_gpu, ns_cpu, caster, fb = _render_both(oracle, vdb, ref, SNAKE_TF, (100, 90, 70), (1, 1, 1),
+                                                             160, 120, orbit=orbit, max_alpha=max_alpha)
+        assert ns_gpu == ns_cpu and ns_cpu > 10_000
+        _check_images(got, want)
+        fb2 = FrameBuffer(160, 120, DEV)
+        caster.RenderDepthBoxVDB(fb2)
+        torch.cuda.synchronize()
+        assert fb2.ReadBack().tobytes() == got.tobytes()
+
+
 def test_row_split_gives_the_same_frame(oracle):
     dim = (64, 128, 128)
     vol = syn.head_volume(dim)
