@@ -59,6 +59,20 @@ def test_kingsnake_4k_build_and_frame_bands(oracle):
         assert ns > 100_000, "the band must cross the tube"
         _check_images(got, want[y0:y0 + 24])
         assert got[..., 3].max() > 200
+    # whole frames round the orbit: the kernel made for 36-voxel bricks (no counters) against the general
+    # one (with counters), byte for byte, and the same number of samples from both ends of the turn
+    fb2 = FrameBuffer(W, H, DEV)
+    for orbit in (0, 97, 188, 290, 368, 511, 655):
+        w2s, c, proj = dvr_setup(dim, (1, 1, 1), W, H, orbit_steps=orbit)
+        caster.SetWorldToScene(w2s)
+        caster.SetProjection(proj)
+        caster.SetCameraToWorld(c.pos, c.rotation())
+        caster.RenderDepthBoxVDB(fb)
+        counters = torch.zeros(2, dtype=torch.int64, device=DEV)
+        caster.RenderDepthBoxVDB(fb2, counters=counters)
+        torch.cuda.synchronize()
+        assert int(counters[0]) > 10_000_000
+        assert torch.equal(fb.rgba, fb2.rgba), f"frames differ at orbit step {orbit}"
 
 
 def test_ten_million_triangles_tree_and_262144_rays(oracle):
