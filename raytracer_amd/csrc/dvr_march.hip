@@ -616,38 +616,49 @@ __global__ __launch_bounds__(THREADS) void dvr_kernel(const kk_vdb_device_data v
                             // loop with one way out and no flag to carry; a limit of zero or less (one sample per
                             // ray) keeps the reference's form.
                             if (!SHADING && !COUNT && rp.max_alpha > 0.f) {
-                                // The same loop with the taps of the next sample asked for before the present
-                                // one is mixed and composited (its position does not depend on the colour): the
-                                // loads' way through the caches runs beside the table lookups and the
-                                // arithmetic of the sample before. A ray that ends has asked for eight bytes it
-                                // does not use (the offset is clamped into the brick whatever the position).
+                                // The same loop in three stages: the voxels of the sample after next are asked
+                                // for, the next sample is mixed and its colour looked up, and the present one is
+                                // composited - only the compositing and the opacity test depend on the sample
+                                // before, so the loads' way through the caches and the table lookups in LDS run
+                                // beside the arithmetic of other samples. Two samples per pass, each stage's
+                                // values in variables of their own, so nothing is copied. A ray that ends has
+                                // fetched two samples and looked up one that it does not use (offsets are clamped
+                                // into the brick whatever the position); its position is not used after the loop.
                                 auto fetch = [&]() {
                                     return fetchTaps<T, FLOAT_OFFSETS>(sampleBase, A, originLin,
                                                                        atlasBrickMinVoxPos + posInBrick, sampleOff);
                                 };
-                                auto composite = [&](const Taps<T> &t) {
-                                    const TfPairs tfc = tfLookupPairs(s_tf, mixTaps<T>(t, norm));
+                                auto lookup = [&](const Taps<T> &t) { return tfLookupPairs(s_tf, mixTaps<T>(t, norm)); };
+                                auto blend = [&](const TfPairs &tfc) {
                                     const float wgt = (1.f - a) * tfc.ba.y;
                                     const v2f rg = v2f{rgb.x, rgb.y} + v2f{wgt, wgt} * tfc.rg;
                                     rgb = {rg.x, rg.y, rgb.z + wgt * tfc.ba.x};
                                     a = a + wgt;
                                 };
+                                auto stepOn = [&]() {
+                                    param.tCurr += step;
+                                    posInBrick = posInBrick + dltPos;
+                                };
                                 if (inBrick() & !(a >= rp.max_alpha)) {
-                                    Taps<T> even = fetch(), odd;
+                                    Taps<T> t0 = fetch();
+                                    stepOn();
+                                    bool v1 = inBrick(), v2;
+                                    Taps<T> t1 = fetch();
+                                    TfPairs c0 = lookup(t0), c1;
                                     while (true) {
-                                        param.tCurr += step;
-                                        posInBrick = posInBrick + dltPos;
-                                        bool more = inBrick();
-                                        odd = fetch();
-                                        composite(even);
-                                        if (!(more & !(a >= rp.max_alpha)))
+                                        stepOn();
+                                        v2 = inBrick();
+                                        t0 = fetch();
+                                        c1 = lookup(t1);
+                                        blend(c0);
+                                        if (!(v1 & !(a >= rp.max_alpha)))
                                             break;
-                                        param.tCurr += step;
-                                        posInBrick = posInBrick + dltPos;
-                                        more = inBrick();
-                                        even = fetch();
-                                        composite(odd);
-                                        if (!(more & !(a >= rp.max_alpha)))
+                                        stepOn();
+                                        v1 = inBrick();
+                                        t1 = fetch();
+                                        c0 = lookup(t0);
+                                        blend(c1);
+                                        if (!(v2 & !(a >= rp.max_alpha)))
                                             break;
                                     }
                                 }
