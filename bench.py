@@ -43,8 +43,8 @@ LBVH_BYTES_PER_TRI = 368
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)  # 0.25 s: one host hiccup of a few ms is not the result
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--tris", type=int, default=10_000_000)
     ap.add_argument("--rays", type=int, default=2_097_152)
     ap.add_argument("--cpu-rays", type=int, default=262_144, help="rays of the CPU baseline sample")
@@ -138,6 +138,9 @@ def main():
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
+    import gc
+    gc.collect()
+    gc.disable()  # (a collection inside the timed region would be host time, not the path's)
     t0 = time.perf_counter()
     for _ in range(K):
         closest_hit(bvh, rays, out=l_out)
@@ -145,6 +148,7 @@ def main():
     if dist:
         dist.barrier()
     wall = time.perf_counter() - t0
+    gc.enable()
     if dist:
         tt = torch.tensor([wall], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)

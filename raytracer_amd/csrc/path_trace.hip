@@ -274,6 +274,7 @@ KK_D f3 renderScene(const Tracer &tracer, const kk_pt_scene &p, Rng &rng, Ray ra
     return Lo;
 }
 
+#ifndef KK_PT_SHORT_ONLY
 template <bool WIDE>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(5, 5))) void path_trace_kernel(
     const kk_lbvh_device_data *__restrict__ lbvh, const accel::View view, const kk_pt_scene p,
@@ -374,6 +375,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(5, 5)))
 // costs the wave as much as one run for all; the few wait a walk phase longer instead. A lane computes
 // its path with the same operations in the same order as renderScene above, and the random stream is
 // keyed by (pixel, sample, sampling event), so the image does not depend on the scheduling.
+#endif // KK_PT_SHORT_ONLY
 namespace persist {
 
 enum : uint32_t {
@@ -410,7 +412,9 @@ constexpr uint32_t COUNTER_SLOTS = 64;
 // PIXEL_QUEUES-th tile each, so that all hold the same mix of cheap and costly pixels; a wave starts at
 // the queue of its XCD and moves on when that is used up), their heads 128 bytes apart.
 constexpr uint32_t PIXEL_QUEUES = 8, HEAD_STRIDE = 32, SLOT_WORDS = PIXEL_QUEUES * HEAD_STRIDE;
+#ifndef KK_PT_SHORT_ONLY
 static __device__ uint32_t g_pixelQueue[COUNTER_SLOTS * SLOT_WORDS];
+#endif
 
 struct PathState {
     // the path
@@ -877,6 +881,38 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(WAVES, 
     }
 }
 
+// The variants with WAVES_SHORT waves per SIMD live in an object file of their own: this source compiled with
+// KK_PT_SHORT_ONLY under the scheduler that suits them (the Makefile has the measurements), which leaves
+// nothing but this launcher in it.
+void launch_short_variant(bool count, bool stripes, uint32_t grid, hipStream_t stream, const accel::View &view,
+                          const kk_pt_scene &scene, const kk_pt_frame &frame, float *accum, uint8_t *rgba, int W,
+                          int H, int y0, int y1, float sampleIdx, int sampleCount, uint32_t seed,
+                          uint32_t *pixelQueue, unsigned long long *counters, int stripeFirst, int stripeStride);
+#ifdef KK_PT_SHORT_ONLY
+void launch_short_variant(bool count, bool stripes, uint32_t grid, hipStream_t stream, const accel::View &view,
+                          const kk_pt_scene &scene, const kk_pt_frame &frame, float *accum, uint8_t *rgba, int W,
+                          int H, int y0, int y1, float sampleIdx, int sampleCount, uint32_t seed,
+                          uint32_t *pixelQueue, unsigned long long *counters, int stripeFirst, int stripeStride) {
+#define KK_SHORT(COUNT, STRIPES)                                                                       \
+    path_trace_persistent_kernel<COUNT, persist::WAVES_SHORT, STRIPES><<<grid, THREADS, 0, stream>>>(  \
+        view, scene, frame, accum, rgba, W, H, y0, y1, sampleIdx, sampleCount, seed, pixelQueue, counters, \
+        stripeFirst, stripeStride)
+    if (count) {
+        if (stripes)
+            KK_SHORT(true, true);
+        else
+            KK_SHORT(true, false);
+    } else {
+        if (stripes)
+            KK_SHORT(false, true);
+        else
+            KK_SHORT(false, false);
+    }
+#undef KK_SHORT
+}
+} // namespace pt
+} // namespace kk
+#else
 __global__ void rng_uniforms_kernel(uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t count,
                                     float *out) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -977,17 +1013,14 @@ static int render_samples(const kk_lbvh_device_data *d_lbvh, const kk_pt_scene *
         else                                                                                           \
             KK_LAUNCH_PT(COUNT, WAVES, false);                                                         \
     } while (0)
-        if (dbg) {
-            if (longLaunch)
-                KK_LAUNCH_PT2(true, persist::WAVES_LONG);
-            else
-                KK_LAUNCH_PT2(true, persist::WAVES_SHORT);
-        } else {
-            if (longLaunch)
-                KK_LAUNCH_PT2(false, persist::WAVES_LONG);
-            else
-                KK_LAUNCH_PT2(false, persist::WAVES_SHORT);
-        }
+        if (!longLaunch)
+            launch_short_variant(dbg != nullptr, stripes, pgrid, stream, view, *h_scene, *h_frame, d_accum, d_rgba,
+                                 width, height, y0, y1, sample_index, sample_count, seed, head, dbg, stripeFirst,
+                                 stripeStride);
+        else if (dbg)
+            KK_LAUNCH_PT2(true, persist::WAVES_LONG);
+        else
+            KK_LAUNCH_PT2(false, persist::WAVES_LONG);
 #undef KK_LAUNCH_PT2
 #undef KK_LAUNCH_PT
     } else
@@ -1054,3 +1087,4 @@ extern "C" int kk_rng_uniforms(uint32_t seed, uint32_t pixel, uint32_t sample, u
     KK_LAUNCH_CHECK();
     return KK_OK;
 }
+#endif // KK_PT_SHORT_ONLY
