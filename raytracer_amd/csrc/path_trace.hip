@@ -57,6 +57,15 @@ struct Rng {
     }
 };
 
+// x^y for x >= 0 where only a magnitude depends on it (the specular lobe's value and density, the tone curve):
+// exp2(y log2 x) on the hardware's log2 and exp2, a few parts in a million off the library's powf against the
+// 1e-3 the images are compared within, at four instructions instead of about a hundred. (x = 0 gives 0 for
+// y > 0, y = 0 gives 1, as powf does.) The direction of a specular bounce keeps powf: a direction decides
+// what a ray hits.
+KK_D float magnitudePow(float x, float y) {
+    const float r = __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x));
+    return y == 0.f ? 1.f : r;
+}
 KK_D f3 V(const float *p) { return {p[0], p[1], p[2]}; }
 
 // include/cg/math.h:95-129
@@ -86,7 +95,7 @@ KK_D f3 BRDF(const kk_material &m, f3 dirIn, f3 dirOut, f3 norm) {
     const f3 diffuse = V(m.kd) * OneOverPi;
     const f3 reflect = normalize(2.f * dot(norm, dirOut) * norm - dirOut);
     const f3 specular =
-        V(m.ks) * (m.ns + 2.f) * OneOverTwoPi * powf(gmax(dot(dirIn, reflect), 0.f), m.ns);
+        V(m.ks) * (m.ns + 2.f) * OneOverTwoPi * magnitudePow(gmax(dot(dirIn, reflect), 0.f), m.ns);
     return diffuse + specular;
 }
 
@@ -257,7 +266,7 @@ KK_D f3 renderScene(const Tracer &tracer, const kk_pt_scene &p, Rng &rng, Ray ra
             ray.dir = ThetaPhiToDirection(acosf(powf(u0, 1.f / (matr.ns + 1.f))), TwoPi * u1, reflect,
                                           tngnt);
             pdfIndrct = (matr.ns + 1.f) * OneOverTwoPi *
-                        powf(gmax(dot(reflect, ray.dir), 0.f), matr.ns) *
+                        magnitudePow(gmax(dot(reflect, ray.dir), 0.f), matr.ns) *
                         (1.f - matr.kd_over_kd_add_ks);
         }
         Lo = Lo + throughout * Li;
@@ -268,9 +277,9 @@ KK_D f3 renderScene(const Tracer &tracer, const kk_pt_scene &p, Rng &rng, Ray ra
     }
     // HDRToLDRCorrect + GammaCorrect, include/cg/math.h:75-93
     Lo = Lo / (Lo + 1.f);
-    Lo.x = powf(Lo.x, 1.f / 2.2f);
-    Lo.y = powf(Lo.y, 1.f / 2.2f);
-    Lo.z = powf(Lo.z, 1.f / 2.2f);
+    Lo.x = magnitudePow(Lo.x, 1.f / 2.2f);
+    Lo.y = magnitudePow(Lo.y, 1.f / 2.2f);
+    Lo.z = magnitudePow(Lo.z, 1.f / 2.2f);
     return Lo;
 }
 
@@ -714,7 +723,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(WAVES, 
                     ray.dir = ThetaPhiToDirection(acosf(powf(u0, 1.f / (matr.ns + 1.f))), TwoPi * u1, reflect,
                                                   tngnt);
                     pdfIndrct = (matr.ns + 1.f) * OneOverTwoPi *
-                                powf(gmax(dot(reflect, ray.dir), 0.f), matr.ns) *
+                                magnitudePow(gmax(dot(reflect, ray.dir), 0.f), matr.ns) *
                                 (1.f - matr.kd_over_kd_add_ks);
                 }
                 ps.Lo = ps.Lo + ps.throughout * ps.Li;
@@ -742,9 +751,9 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(WAVES, 
             // tone curve, running mean, RGBA8 (:428-429, 623-637)
             if (stage == ST_END) {
                 f3 Lo = ps.Lo / (ps.Lo + 1.f);
-                Lo.x = powf(Lo.x, 1.f / 2.2f);
-                Lo.y = powf(Lo.y, 1.f / 2.2f);
-                Lo.z = powf(Lo.z, 1.f / 2.2f);
+                Lo.x = magnitudePow(Lo.x, 1.f / 2.2f);
+                Lo.y = magnitudePow(Lo.y, 1.f / 2.2f);
+                Lo.z = magnitudePow(Lo.z, 1.f / 2.2f);
                 const uint32_t idx = STRIPES ? outPixel : ps.pixel;
                 const f3 prev = {accum[3ull * idx], accum[3ull * idx + 1], accum[3ull * idx + 2]};
                 const f3 color = prev + (Lo - prev) / static_cast<float>(ps.sample);
