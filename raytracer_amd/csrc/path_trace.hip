@@ -79,14 +79,19 @@ KK_D f3 FrameToWorld(f3 dir, f3 norm, f3 tngnt) {
     const m3 m{{tngnt, biTngnt, norm}};
     return normalize(m * dir);
 }
+// (sine and cosine of one angle from one call: the same values as sinf and cosf give, one argument reduction)
 KK_D f3 ThetaPhiToDirection(float theta, float phi, f3 norm, f3 tngnt) {
-    const float sinTheta = sinf(theta);
-    const f3 dir = {cosf(phi) * sinTheta, sinf(phi) * sinTheta, cosf(theta)};
+    float sinTheta, cosTheta, sinPhi, cosPhi;
+    sincosf(theta, &sinTheta, &cosTheta);
+    sincosf(phi, &sinPhi, &cosPhi);
+    const f3 dir = {cosPhi * sinTheta, sinPhi * sinTheta, cosTheta};
     return FrameToWorld(dir, norm, tngnt);
 }
 KK_D f3 CosineThetaPhiToDirection(float cosTheta, float phi, f3 norm, f3 tngnt) {
     const float sinTheta = sqrtf(gmin(gmax(1.f - cosTheta * cosTheta, 0.f), 1.f));
-    const f3 dir = {cosf(phi) * sinTheta, sinf(phi) * sinTheta, cosTheta};
+    float sinPhi, cosPhi;
+    sincosf(phi, &sinPhi, &cosPhi);
+    const f3 dir = {cosPhi * sinTheta, sinPhi * sinTheta, cosTheta};
     return FrameToWorld(dir, norm, tngnt);
 }
 
